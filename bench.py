@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""bench.py — frames/sec of the rtpose hot path on MI355X (BASELINE.json metric).
+
+A "step" = one frame: net input (num_scales x 3 x 368 x 656 fp32, already resident in HBM) ->
+conv stack -> ImResize -> Nms -> connectLimbsCOCO -> joints on the host.  Workload = BASELINE.json
+configs[1] ("COCO model 656x368, 1 scale, 1xMI355X") unless --num_scales says otherwise.
+Multi-GPU: one process per GPU, frames sharded (replicas, no data-path collective) — weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def cpu_baseline(eng, num_scales):
+    """The CPU oracle (a port: the reference itself cannot be built here) timed on this host's cores
+    on a bounded sample: ONE frame through conv stack + ImResize + NMS + connect."""
+    import numpy as np
+    import _oracle as orc
+    import _synth
+    net = orc.Net(0)
+    for i in range(len(net.convs)):
+        w, b = eng.get_conv_weights(i)
+        net.set_weights(i, w, b)
+    x = _synth.random_frame(num_scales, 368, 656, seed=1)
+    t0 = time.time()
+    low = net.forward(x)
+    t1 = time.time()
+    res = orc.imresize(low, 656, 368, 1.0, 0.3)[0]
+    peaks = orc.nms(res, 18, 64, 0.05)
+    orc.connect(0, res, peaks, 64, 656, 368, 1280, 720)
+    t2 = time.time()
+    return {"value": 1.0 / (t2 - t0), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"1 frame, {num_scales} scale(s), 656x368 COCO: conv stack {t1 - t0:.2f}s + postproc {t2 - t1:.2f}s, OpenMP fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--num_scales", type=int, default=1)
+    ap.add_argument("--scale_gap", type=float, default=0.3)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--in_flight", type=int, default=4)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import caffe_rtpose_amd as r
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    seed = 1
+    prec = r.PREC_FP16 if args.precision == "fp16" else r.PREC_FP32
+    eng = r.Engine(r.Config(device_id=local, model=r.MODEL_COCO_18, net_w=656, net_h=368, num_scales=args.num_scales,
+                            scale_gap=args.scale_gap, precision=prec, frames_in_flight=args.in_flight, synthetic_seed=seed))
+    # synthetic frames, resident in HBM before the timed region (u8/256-0.5 like process_and_pad_image)
+    nframes = 8
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    frames = [(torch.randint(0, 256, (args.num_scales, 3, 368, 656), generator=g).float() / 256.0 - 0.5).cuda() for _ in range(nframes)]
+    torch.cuda.synchronize()
+
+    def run(nsteps, base_tag):
+        sub = col = 0
+        people = 0
+        while col < nsteps:
+            while sub < nsteps and eng.in_flight() < args.in_flight:
+                eng.submit_device(frames[sub % nframes].data_ptr(), tag=base_tag + sub)
+                sub += 1
+            tag, n, _ = eng.collect()
+            assert tag == base_tag + col
+            people += n
+            col += 1
+        return people
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, 1 << 20)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stage = eng.last_stage_ms()
+
+    if rank == 0:
+        # dominant kernel: the paired 7x7 128->128 convolution (40 of the 92 layers, 50% of all FLOPs);
+        # HIP events on the engine's own stream around `iters` back-to-back launches.
+        ms, flops = eng.bench_dominant_conv(iters=200)
+        peak = 2.5e15 if args.precision == "fp16" else 157.3e12
+        achieved = flops / (ms * 1e-3)
+        roof = {"bound": "mfma", "kernel": "conv_igemm 7x7 128->128 (L1+L2 pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "ms_per_launch": ms, "flops_per_launch": flops}
+        fps = world * args.steps / dt
+        whole = {"achieved": fps / world * 484.634e9 * args.num_scales / 1e12, "unit": "TFLOP/s",
+                 "frac": fps / world * 484.634e9 * args.num_scales / peak}
+        out = {
+            "metric": "frames/sec (whole node) at 656x368 COCO model",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": f"COCO 656x368, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU, synthetic weights",
+                       "parallelism": f"frame-sharded replicas x{world}"},
+            "stage_ms_last_frame": stage, "roofline": roof, "conv_stack_whole_frame": whole,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(eng, args.num_scales)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""Loads librtpose_mi355x.so.  No fallback of any kind."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtpose_mi355x.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP engine first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C caffe_rtpose_amd/csrc). "
+        "There is no CPU/PyTorch fallback for this path.")
+
+lib = C.CDLL(LIB_PATH)
+
+
+class rtp_config(C.Structure):
+    _fields_ = [
+        ("device_id", C.c_int),
+        ("model", C.c_int),
+        ("proto_path", C.c_char_p),
+        ("weights_path", C.c_char_p),
+        ("synthetic_seed", C.c_uint64),
+        ("net_w", C.c_int),
+        ("net_h", C.c_int),
+        ("num_scales", C.c_int),
+        ("start_scale", C.c_float),
+        ("scale_gap", C.c_float),
+        ("disp_w", C.c_int),
+        ("disp_h", C.c_int),
+        ("precision", C.c_int),
+        ("frames_in_flight", C.c_int),
+    ]
+
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+# every symbol include/rtpose_mi355x.h declares, with its signature
+SIGNATURES = {
+    "rtp_config_default": (C.c_int, [C.POINTER(rtp_config)]),
+    "rtp_engine_create": (C.c_int, [C.POINTER(rtp_config), C.POINTER(vp)]),
+    "rtp_engine_destroy": (None, [vp]),
+    "rtp_engine_info": (C.c_int, [vp, ip, ip, ip, ip, ip]),
+    "rtp_set_thresholds": (C.c_int, [vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]),
+    "rtp_get_thresholds": (C.c_int, [vp, fp, fp, ip, ip, fp]),
+    "rtp_set_scales": (C.c_int, [vp, C.c_float, C.c_float]),
+    "rtp_submit": (C.c_int, [vp, fp, C.c_uint64]),
+    "rtp_submit_device": (C.c_int, [vp, vp, C.c_uint64]),
+    "rtp_collect": (C.c_int, [vp, C.POINTER(C.c_uint64), fp, ip]),
+    "rtp_in_flight": (C.c_int, [vp]),
+    "rtp_forward_heatmaps": (C.c_int, [vp, fp, fp]),
+    "rtp_resize": (C.c_int, [vp, fp, fp]),
+    "rtp_nms": (C.c_int, [vp, fp, fp]),
+    "rtp_connect": (C.c_int, [vp, fp, fp, fp, ip]),
+    "rtp_forward_debug": (C.c_int, [vp, fp, fp, fp, fp, fp, ip]),
+    "rtp_get_blob": (C.c_int, [vp, C.c_char_p, fp, C.c_size_t, ip]),
+    "rtp_num_conv_layers": (C.c_int, [vp]),
+    "rtp_conv_layer_info": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, ip, ip, ip]),
+    "rtp_get_conv_weights": (C.c_int, [vp, C.c_int, fp, fp]),
+    "rtp_set_conv_weights": (C.c_int, [vp, C.c_int, fp, fp]),
+    "rtp_save_caffemodel": (C.c_int, [vp, C.c_char_p]),
+    "rtp_save_prototxt": (C.c_int, [vp, C.c_char_p]),
+    "rtp_model_tables": (C.c_int, [C.c_int, ip, ip, ip, ip]),
+    "rtp_default_thresholds": (C.c_int, [C.c_int, fp, fp, ip, ip, fp]),
+    "rtp_process_and_pad_image": (C.c_int, [fp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rtp_format_json": (C.c_long, [C.c_char_p, C.c_size_t, fp, C.c_int, C.c_int, C.c_float]),
+    "rtp_prototxt_summary": (C.c_int, [C.c_char_p, ip, ip, ip, ip, fp, ip]),
+    "rtp_last_error": (C.c_char_p, [vp]),
+    "rtp_version": (C.c_char_p, []),
+    "rtp_last_stage_ms": (C.c_int, [vp, fp]),
+    "rtp_synth_weights": (C.c_int, [C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_int, fp, fp]),
+    "rtp_write_synthetic_caffemodel": (C.c_int, [C.c_int, C.c_uint64, C.c_char_p]),
+    "rtp_caffemodel_layer": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_long), C.POINTER(C.c_long), fp]),
+    "rtp_plan_summary": (C.c_long, [C.POINTER(rtp_config), C.c_char_p, C.c_size_t]),
+    "rtp_bench_dominant_conv": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_double)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args

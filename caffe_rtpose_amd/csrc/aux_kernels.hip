@@ -1,0 +1,131 @@
+// aux_kernels.hip — the HBM-bound glue of the conv stack: input packing, 2x2 max pooling and
+// the debug export.  All are pure streaming kernels: 16-byte vector accesses, one pass.
+#include "kernels.h"
+
+namespace rtp {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+// ---- input pack: NCHW fp32 image -> 3x3 im2col, 32 channels, halo'd NHWC -------------------
+// Replaces the H2D'd blobs()[0] (rtpose.cpp:1131-1133) as conv1_1's input: with the 27 taps of
+// the Cin=3 first layer laid out as channels, conv1_1 becomes a 1x1 convolution with K=32 and
+// runs on the same MFMA kernel as every other layer (model/coco/pose_deploy_linevec.prototxt:6-28).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ in, T* __restrict__ out,
+                                                          Geom g, int Cp) {
+  const long total = (long)g.N * g.H * g.W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % g.W);
+    const int y = (int)((idx / g.W) % g.H);
+    const int n = (int)(idx / ((long)g.W * g.H));
+    const float* ip = in + (long)n * 3 * g.H * g.W;
+    T vals[32];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int yy = y + r - 1, xx = x + s - 1;
+        const bool ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          vals[(r * 3 + s) * 3 + c] = ok ? (T)ip[((long)c * g.H + yy) * g.W + xx] : (T)0.f;
+      }
+#pragma unroll
+    for (int j = 27; j < 32; ++j) vals[j] = (T)0.f;
+    T* op = out + (((long)n * g.Hp + y + g.halo) * g.Wp + x + g.halo) * Cp;
+    constexpr int VEC = 16 / sizeof(T);
+#pragma unroll
+    for (int v = 0; v < 32 / VEC; ++v) {
+      uint4 pk;
+      __builtin_memcpy(&pk, &vals[v * VEC], 16);
+      *(uint4*)(op + v * VEC) = pk;
+    }
+  }
+}
+
+hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, int Cp, hipStream_t stream) {
+  const long total = (long)g.N * g.H * g.W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (prec == 0) hipLaunchKernelGGL(pack_input_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, in_nchw, (_Float16*)out, g, Cp);
+  else hipLaunchKernelGGL(pack_input_kernel<float>, dim3(blocks), dim3(256), 0, stream, in_nchw, (float*)out, g, Cp);
+  return hipGetLastError();
+}
+
+// ---- 2x2 / stride 2 MAX pooling (pooling_layer.cpp:140-180; resolutions are even) ----------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, Geom gi, int Cpi, T* __restrict__ out,
+                                                       Geom go, int Cpo, int C) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cv = C / VEC;
+  const long total = (long)go.N * go.H * go.W * cv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * VEC;
+    long p = idx / cv;
+    const int x = (int)(p % go.W);
+    p /= go.W;
+    const int y = (int)(p % go.H);
+    const int n = (int)(p / go.H);
+    const T* ip = in + (((long)n * gi.Hp + 2 * y + gi.halo) * gi.Wp + 2 * x + gi.halo) * Cpi + c;
+    uint4 q00 = *(const uint4*)ip;
+    uint4 q01 = *(const uint4*)(ip + Cpi);
+    uint4 q10 = *(const uint4*)(ip + (long)gi.Wp * Cpi);
+    uint4 q11 = *(const uint4*)(ip + (long)gi.Wp * Cpi + Cpi);
+    T a[VEC], b[VEC], cc[VEC], d[VEC], o[VEC];
+    __builtin_memcpy(a, &q00, 16);
+    __builtin_memcpy(b, &q01, 16);
+    __builtin_memcpy(cc, &q10, 16);
+    __builtin_memcpy(d, &q11, 16);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      T m = a[i];
+      m = b[i] > m ? b[i] : m;
+      m = cc[i] > m ? cc[i] : m;
+      m = d[i] > m ? d[i] : m;
+      o[i] = m;
+    }
+    uint4 r;
+    __builtin_memcpy(&r, o, 16);
+    *(uint4*)(out + (((long)n * go.Hp + y + go.halo) * go.Wp + x + go.halo) * Cpo + c) = r;
+  }
+}
+
+hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C,
+                          hipStream_t stream) {
+  const int vec = prec == 0 ? 8 : 4;
+  const long total = (long)go.N * go.H * go.W * (C / vec);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C);
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C);
+  return hipGetLastError();
+}
+
+// ---- debug export: halo'd NHWC -> planar fp32 NCHW (Net::blob_by_name()->cpu_data() tap) ----
+template <typename T>
+__global__ __launch_bounds__(256) void export_kernel(const T* __restrict__ in, Geom g, int Cp, const int* __restrict__ chmap,
+                                                      int C, float* __restrict__ out) {
+  const long total = (long)g.N * C * g.H * g.W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % g.W);
+    long p = idx / g.W;
+    const int y = (int)(p % g.H);
+    p /= g.H;
+    const int c = (int)(p % C);
+    const int n = (int)(p / C);
+    const int ci = chmap ? chmap[c] : c;
+    out[idx] = (float)in[(((long)n * g.Hp + y + g.halo) * g.Wp + x + g.halo) * Cp + ci];
+  }
+}
+
+hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, float* out,
+                         hipStream_t stream) {
+  const long total = (long)g.N * C * g.H * g.W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (prec == 0) hipLaunchKernelGGL(export_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, g, Cp, chmap_dev, C, out);
+  else hipLaunchKernelGGL(export_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, g, Cp, chmap_dev, C, out);
+  return hipGetLastError();
+}
+
+}  // namespace rtp

@@ -1,0 +1,1223 @@
+// engine.cpp — static execution plan + frame contexts behind the C-ABI of include/rtpose_mi355x.h.
+//
+// Replaces the Caffe net runtime on the rtpose path (net.cpp:49 Net::Init, :544-556
+// ForwardFromTo, syncedmem.cpp:25-77) with a plan that is compiled ONCE per
+// (graph, resolution, num_scales, precision):
+//   * every blob gets a halo'd NHWC tensor in a per-context arena (kernels.h), zeroed once;
+//   * ReLU is folded into the producing convolution, Concat is eliminated by letting producers
+//     write straight into channel slices of the consumer's tensor (multi-destination epilogue),
+//     Split is a pointer share;
+//   * the independent L1/L2 branch convolutions of a stage are paired into one launch;
+//   * weights are re-laid out per layer for the kernel's [tap][chunk][cout][k] staging order;
+//   * frames_in_flight contexts (stream + arena) let consecutive frames overlap, which is what
+//     fills 256 CUs when one frame's layers are too small to.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/rtpose_mi355x.h"
+#include "kernels.h"
+#include "netdef.h"
+
+using namespace rtp;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct Tensor {
+  std::string name;
+  int C = 0, Cp = 0, level = 0;
+  size_t offset = 0;        // byte offset of padded pixel 0 of image 0 inside a context arena
+  std::vector<int> chmap;   // reference channel -> internal channel
+};
+
+struct ConvOp {
+  std::string name;
+  int widx = 0;             // index into engine weights
+  int in_tensor = -1;
+  int k = 1, k_eff = 1;     // k_eff = 1 for the im2col-packed first layer
+  int cin = 0, cout = 0;
+  bool relu = false, first = false;
+  std::vector<std::pair<int, int>> dsts;  // (tensor, channel offset)
+  bool to_lowres = false;
+  int lowres_coff = 0;
+  int level = 0;
+  int Cin_p = 0, rowb = 128, nchunk = 1, CoutP = 0, cfg = 0;
+  size_t w_off = 0, b_off = 0, w_bytes = 0;
+};
+
+struct Step {
+  int type;  // 0 pack, 1 conv, 2 pool
+  int a = -1, b = -1;
+};
+
+struct PoolOp { int in_tensor, out_tensor, C; };
+
+struct Ctx {
+  hipStream_t stream = nullptr;
+  unsigned char* arena = nullptr;
+  float* input = nullptr;     // device NCHW fp32
+  float* host_in = nullptr;   // pinned staging
+  float* lowres = nullptr;
+  float* resized = nullptr;
+  float* peaks = nullptr;
+  int* strip_count = nullptr;
+  int* strip_list = nullptr;
+  float* cand_score = nullptr;
+  int* cand_ij = nullptr;
+  int* cand_count = nullptr;
+  int* conn = nullptr;
+  float* conn_score = nullptr;
+  int* conn_count = nullptr;
+  float* joints = nullptr;
+  int* num_people = nullptr;
+  float* host_out = nullptr;  // pinned: [1 int as float slot][joints]
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint64_t tag = 0;
+  bool busy = false;
+};
+
+}  // namespace
+
+struct rtp_engine {
+  rtp_config cfg;
+  std::string proto_path, weights_path;
+  NetDef net;
+  int model = 0, prec = 0, elem = 2;
+  int num_parts = 18, max_peaks = 64, heat_channels = 57, num_limbs = 19;
+  int low_w = 0, low_h = 0;
+  float nms_threshold = 0.05f, inter_threshold = 0.05f, min_subset_score = 0.4f;
+  int inter_min_above = 9, min_subset_cnt = 3;
+  float start_scale = 1.f, scale_gap = 0.3f;
+  int N = 1;
+  Geom geom[8];
+  int nlevels = 0;
+  std::vector<Tensor> tensors;
+  std::map<std::string, int> blob_tensor;                 // blob name -> tensor (NHWC blobs)
+  std::map<std::string, std::pair<int, int>> blob_dims;   // blob name -> (C, level)
+  std::string lowres_blob;
+  std::vector<ConvOp> convs;
+  std::vector<Step> steps;
+  std::vector<PoolOp> pools;
+  std::vector<std::vector<float>> w_ref, b_ref;           // Caffe layout per conv
+  size_t arena_bytes = 0, weights_bytes = 0;
+  unsigned char* dweights = nullptr;
+  int* dchmap = nullptr;  // scratch for export
+  std::vector<Ctx> ctx;
+  std::deque<int> fifo;
+  int nstrips = 0, strip_rows = 8, max_rows = 0;
+  float last_ms[5] = {0, 0, 0, 0, 0};
+  std::string err;
+  int dominant_step = -1;
+};
+
+namespace {
+
+int fail(rtp_engine* e, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(e, call)                                                                             \
+  do {                                                                                              \
+    hipError_t _s = (call);                                                                         \
+    if (_s != hipSuccess)                                                                           \
+      return fail((e), RTP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_s), __FILE__, __LINE__); \
+  } while (0)
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+inline size_t round_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+const int GUARD_PIX = 192;  // pixels of slack before/after each tensor (strip over-read of the last tile)
+
+// ---- plan ---------------------------------------------------------------------------------
+int build_plan(rtp_engine* e) {
+  const NetDef& net = e->net;
+  const int CALIGN = 128 / e->elem;
+  e->blob_dims.clear();
+  if (net.inputs.empty()) return fail(e, RTP_EINVAL, "prototxt declares no input blob");
+  const std::string in_name = net.inputs[0];
+  e->blob_dims[in_name] = {3, 0};
+  struct ConcatInfo { std::vector<std::string> inputs; };
+  std::map<std::string, ConcatInfo> concats;
+  std::map<std::string, int> producer_conv;  // blob -> conv index
+  std::vector<int> level_halo(8, 0);
+  int max_level = 0;
+  bool have_resize = false, have_nms = false;
+  struct PoolTmp { std::string in, out; };
+  std::vector<std::pair<int, int>> order;  // (kind 1 conv / 2 pool, index)
+  std::vector<PoolTmp> pools;
+
+  for (size_t li = 0; li < net.layers.size(); ++li) {
+    const LayerDef& L = net.layers[li];
+    if (L.type == "Convolution") {
+      if (L.bottoms.size() != 1 || L.tops.size() != 1) return fail(e, RTP_EINVAL, "layer %s: expected 1 bottom/1 top", L.name.c_str());
+      auto it = e->blob_dims.find(L.bottoms[0]);
+      if (it == e->blob_dims.end()) return fail(e, RTP_EINVAL, "layer %s: unknown bottom %s", L.name.c_str(), L.bottoms[0].c_str());
+      if (L.stride != 1 || !(L.kernel == 1 || L.kernel == 3 || L.kernel == 7) || L.pad != (L.kernel - 1) / 2 || !L.bias_term)
+        return fail(e, RTP_EINVAL, "layer %s: only stride-1 'same' convolutions with k in {1,3,7} and a bias are on the linevec path", L.name.c_str());
+      ConvOp c;
+      c.name = L.name; c.k = L.kernel; c.k_eff = L.kernel; c.cin = it->second.first; c.cout = L.num_output;
+      c.level = it->second.second;
+      c.first = (L.bottoms[0] == in_name);
+      if (c.first && !(c.cin == 3 && c.k == 3)) return fail(e, RTP_EINVAL, "layer %s: the input convolution must be 3x3 on 3 channels", L.name.c_str());
+      if (c.first) c.k_eff = 1;
+      c.widx = (int)e->convs.size();
+      level_halo[c.level] = std::max(level_halo[c.level], c.k_eff / 2);
+      e->blob_dims[L.tops[0]] = {c.cout, c.level};
+      producer_conv[L.tops[0]] = (int)e->convs.size();
+      order.push_back({1, (int)e->convs.size()});
+      e->convs.push_back(c);
+    } else if (L.type == "ReLU") {
+      if (L.bottoms.size() != 1 || L.tops.size() != 1 || L.bottoms[0] != L.tops[0] || !producer_conv.count(L.bottoms[0]))
+        return fail(e, RTP_EINVAL, "layer %s: ReLU must be in-place on a convolution output", L.name.c_str());
+      if (L.negative_slope != 0.f) return fail(e, RTP_EINVAL, "layer %s: negative_slope != 0 unsupported", L.name.c_str());
+      e->convs[producer_conv[L.bottoms[0]]].relu = true;
+    } else if (L.type == "Pooling") {
+      auto it = e->blob_dims.find(L.bottoms.empty() ? "" : L.bottoms[0]);
+      if (it == e->blob_dims.end()) return fail(e, RTP_EINVAL, "layer %s: unknown bottom", L.name.c_str());
+      if (L.pool_method != "MAX" || L.pool_kernel != 2 || L.pool_stride != 2 || L.pool_pad != 0)
+        return fail(e, RTP_EINVAL, "layer %s: only MAX 2x2 stride 2 pooling is on the linevec path", L.name.c_str());
+      e->blob_dims[L.tops[0]] = {it->second.first, it->second.second + 1};
+      max_level = std::max(max_level, it->second.second + 1);
+      pools.push_back({L.bottoms[0], L.tops[0]});
+      order.push_back({2, (int)pools.size() - 1});
+    } else if (L.type == "Concat") {
+      if (L.axis != 1) return fail(e, RTP_EINVAL, "layer %s: only channel concat", L.name.c_str());
+      int C = 0, lvl = -1;
+      for (auto& b : L.bottoms) {
+        auto it = e->blob_dims.find(b);
+        if (it == e->blob_dims.end()) return fail(e, RTP_EINVAL, "layer %s: unknown bottom %s", L.name.c_str(), b.c_str());
+        if (!producer_conv.count(b)) return fail(e, RTP_EINVAL, "layer %s: concat inputs must be convolution outputs", L.name.c_str());
+        if (lvl >= 0 && lvl != it->second.second) return fail(e, RTP_EINVAL, "layer %s: concat inputs at different resolutions", L.name.c_str());
+        lvl = it->second.second;
+        C += it->second.first;
+      }
+      e->blob_dims[L.tops[0]] = {C, lvl};
+      concats[L.tops[0]] = ConcatInfo{L.bottoms};
+    } else if (L.type == "ImResize") {
+      if (!e->blob_dims.count(L.bottoms[0])) return fail(e, RTP_EINVAL, "resize: unknown bottom");
+      if (L.factor != 8.f) return fail(e, RTP_EINVAL, "resize: only factor 8 (the net's total stride) is supported");
+      e->lowres_blob = L.bottoms[0];
+      have_resize = true;
+    } else if (L.type == "Nms") {
+      e->num_parts = L.num_parts;
+      e->max_peaks = L.max_peaks;
+      have_nms = true;
+    } else if (L.type == "Split") {
+      // pointer share: alias tops to the bottom
+      for (auto& t : L.tops) e->blob_dims[t] = e->blob_dims[L.bottoms[0]];
+      return fail(e, RTP_EINVAL, "layer %s: explicit Split layers are not expected in a deploy prototxt", L.name.c_str());
+    } else {
+      return fail(e, RTP_EINVAL, "layer %s: type %s is not on the linevec hot path", L.name.c_str(), L.type.c_str());
+    }
+  }
+  if (!have_resize || !have_nms) return fail(e, RTP_EINVAL, "graph must end in ImResize + Nms layers");
+  if (e->num_parts == 18) e->model = RTP_MODEL_COCO_18;
+  else if (e->num_parts == 15) e->model = RTP_MODEL_MPI_15;
+  else return fail(e, RTP_EINVAL, "Unknown number of parts (%d)! Couldn't set model", e->num_parts);  // rtpose.cpp:227
+  e->num_limbs = e->model == 0 ? 19 : 14;
+  if (e->max_peaks < 1 || e->max_peaks > 256) return fail(e, RTP_EINVAL, "max_peaks %d out of range [1,256]", e->max_peaks);
+  e->heat_channels = e->blob_dims[e->lowres_blob].first;
+  if (e->blob_dims[e->lowres_blob].second != 3) return fail(e, RTP_EINVAL, "resize input must be at 1/8 resolution");
+  {
+    const int need = (e->model == 0 ? 57 : 44);
+    if (e->heat_channels != need) return fail(e, RTP_EINVAL, "resize input has %d channels, model needs %d", e->heat_channels, need);
+  }
+
+  // geometry
+  e->nlevels = max_level + 1;
+  if ((e->cfg.net_w % 16) || (e->cfg.net_h % 16) || e->cfg.net_w < 16 || e->cfg.net_h < 16)
+    return fail(e, RTP_EINVAL, "net_resolution %dx%d must be positive multiples of 16", e->cfg.net_w, e->cfg.net_h);
+  for (int l = 0; l < e->nlevels; ++l) {
+    Geom g;
+    g.N = e->N; g.H = e->cfg.net_h >> l; g.W = e->cfg.net_w >> l; g.halo = level_halo[l];
+    g.Hp = g.H + 2 * g.halo; g.Wp = g.W + 2 * g.halo; g.img_pix = (long)g.Hp * g.Wp;
+    e->geom[l] = g;
+  }
+  e->low_w = e->cfg.net_w / 8;
+  e->low_h = e->cfg.net_h / 8;
+
+  // tensors
+  auto new_tensor = [&](const std::string& name, int C, int level) {
+    Tensor t;
+    t.name = name; t.C = C; t.level = level;
+    t.Cp = round_up(C, CALIGN);
+    t.chmap.resize(C);
+    for (int i = 0; i < C; ++i) t.chmap[i] = i;
+    e->tensors.push_back(t);
+    return (int)e->tensors.size() - 1;
+  };
+  // packed im2col input
+  int packed_tensor = -1;
+  {
+    Tensor t;
+    t.name = "__im2col_input"; t.C = 27; t.level = 0; t.Cp = 32;
+    t.chmap.resize(27);
+    for (int i = 0; i < 27; ++i) t.chmap[i] = i;
+    e->tensors.push_back(t);
+    packed_tensor = 0;
+  }
+  for (auto& c : e->convs) e->blob_tensor[c.name] = new_tensor(c.name, c.cout, c.level);
+  for (auto& p : pools) e->blob_tensor[p.out] = new_tensor(p.out, e->blob_dims[p.out].first, e->blob_dims[p.out].second);
+  // concat tensors (those read by convolutions); aligned inputs first
+  std::map<std::string, std::vector<std::pair<std::string, int>>> concat_slices;  // concat -> (input, internal offset)
+  for (auto& kv : concats) {
+    if (kv.first == e->lowres_blob) continue;
+    const auto& ins = kv.second.inputs;
+    std::vector<int> ord(ins.size());
+    for (size_t i = 0; i < ins.size(); ++i) ord[i] = (int)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+      const bool ua = (e->blob_dims[ins[a]].first % 8) != 0, ub = (e->blob_dims[ins[b]].first % 8) != 0;
+      return (int)ua < (int)ub;
+    });
+    std::vector<int> internal_off(ins.size());
+    int off = 0;
+    for (int i : ord) { internal_off[i] = off; off += e->blob_dims[ins[i]].first; }
+    const int tid = new_tensor(kv.first, e->blob_dims[kv.first].first, e->blob_dims[kv.first].second);
+    e->blob_tensor[kv.first] = tid;
+    int refc = 0;
+    for (size_t i = 0; i < ins.size(); ++i) {
+      const int C = e->blob_dims[ins[i]].first;
+      for (int c = 0; c < C; ++c) e->tensors[tid].chmap[refc + c] = internal_off[i] + c;
+      refc += C;
+      concat_slices[kv.first].push_back({ins[i], internal_off[i]});
+    }
+  }
+  e->pools.clear();
+  for (auto& p : pools) {
+    PoolOp po;
+    po.in_tensor = e->blob_tensor.at(p.in);
+    po.out_tensor = e->blob_tensor.at(p.out);
+    po.C = e->tensors[po.out_tensor].C;
+    e->pools.push_back(po);
+  }
+  // conv inputs / destinations
+  for (auto& c : e->convs) {
+    const LayerDef* L = nullptr;
+    for (auto& l : net.layers) if (l.type == "Convolution" && l.name == c.name) L = &l;
+    if (c.first) c.in_tensor = packed_tensor;
+    else {
+      auto it = e->blob_tensor.find(L->bottoms[0]);
+      if (it == e->blob_tensor.end()) return fail(e, RTP_EINVAL, "layer %s: bottom %s has no tensor", c.name.c_str(), L->bottoms[0].c_str());
+      c.in_tensor = it->second;
+    }
+    c.dsts.push_back({e->blob_tensor[c.name], 0});
+    for (auto& cs : concat_slices)
+      for (auto& sl : cs.second)
+        if (sl.first == c.name) c.dsts.push_back({e->blob_tensor[cs.first], sl.second});
+    if ((int)c.dsts.size() > RTP_MAX_DST) return fail(e, RTP_EINVAL, "layer %s feeds %d tensors (max %d)", c.name.c_str(), (int)c.dsts.size(), RTP_MAX_DST);
+    // low-res output (the blob ImResize reads), reference channel order
+    if (c.name == e->lowres_blob) { c.to_lowres = true; c.lowres_coff = 0; }
+    else if (concats.count(e->lowres_blob)) {
+      int off = 0;
+      for (auto& in : concats[e->lowres_blob].inputs) {
+        if (in == c.name) { c.to_lowres = true; c.lowres_coff = off; }
+        off += e->blob_dims[in].first;
+      }
+    }
+    const Tensor& ti = e->tensors[c.in_tensor];
+    c.Cin_p = ti.Cp;
+    c.rowb = (c.Cin_p * e->elem >= 128) ? 128 : 64;
+    if ((c.Cin_p * e->elem) % c.rowb) return fail(e, RTP_EINVAL, "layer %s: internal channel padding error", c.name.c_str());
+    c.nchunk = c.Cin_p * e->elem / c.rowb;
+  }
+
+  // steps + pairing + tile configuration
+  e->steps.clear();
+  e->steps.push_back({0, -1, -1});
+  for (size_t oi = 0; oi < order.size(); ++oi) {
+    if (order[oi].first == 2) { e->steps.push_back({2, order[oi].second, -1}); continue; }
+    const int a = order[oi].second;
+    int b = -1;
+    if (oi + 1 < order.size() && order[oi + 1].first == 1) {
+      const int cand = order[oi + 1].second;
+      const ConvOp& A = e->convs[a];
+      const ConvOp& B = e->convs[cand];
+      bool dep = false;
+      for (auto& d : A.dsts) if (d.first == B.in_tensor) dep = true;
+      if (!dep && A.k_eff == B.k_eff && A.Cin_p == B.Cin_p && A.level == B.level && A.relu == B.relu && A.rowb == B.rowb &&
+          round_up(A.cout, 64) == round_up(B.cout, 64) && e->tensors[A.in_tensor].Cp == e->tensors[B.in_tensor].Cp)
+        b = cand;
+    }
+    e->steps.push_back({1, a, b});
+    if (b >= 0) ++oi;
+  }
+  for (auto& s : e->steps) {
+    if (s.type != 1) continue;
+    ConvOp& A = e->convs[s.a];
+    const Geom& g = e->geom[A.level];
+    const int nprob = s.b >= 0 ? 2 : 1;
+    const int maxcout = std::max(A.cout, s.b >= 0 ? e->convs[s.b].cout : 0);
+    const long M = (long)g.H * g.Wp;
+    std::vector<int> cands;
+    if (A.rowb == 64) cands = {CFG_128x64};
+    else if (maxcout <= 64) cands = {CFG_128x64, CFG_64x64};
+    else cands = {CFG_128x128, CFG_64x128, CFG_64x64};
+    int best = cands.back();
+    long best_wg = -1;
+    bool chosen = false;
+    for (int cf : cands) {
+      const ConvCfgInfo ci = conv_cfg_info(cf);
+      const long wg = ((M + ci.BM - 1) / ci.BM) * e->N * (round_up(maxcout, ci.BN) / ci.BN) * nprob;
+      if (!chosen && wg >= 200) { best = cf; chosen = true; }
+      if (!chosen && wg > best_wg) { best = cf; best_wg = wg; }
+    }
+    const ConvCfgInfo ci = conv_cfg_info(best);
+    for (int idx : {s.a, s.b}) {
+      if (idx < 0) continue;
+      ConvOp& c = e->convs[idx];
+      c.cfg = best;
+      c.CoutP = round_up(maxcout, ci.BN);
+    }
+  }
+
+  // arena layout
+  size_t off = 0;
+  for (auto& t : e->tensors) {
+    const Geom& g = e->geom[t.level];
+    const size_t pix_bytes = (size_t)t.Cp * e->elem;
+    off = round_up_sz(off, 256);
+    off += GUARD_PIX * pix_bytes;
+    off = round_up_sz(off, 256);
+    t.offset = off;
+    off += (size_t)e->N * g.img_pix * pix_bytes + GUARD_PIX * pix_bytes;
+  }
+  e->arena_bytes = round_up_sz(off, 256);
+  // weight arena
+  size_t woff = 0;
+  for (auto& c : e->convs) {
+    c.w_bytes = (size_t)c.k_eff * c.k_eff * c.nchunk * c.CoutP * c.rowb;
+    woff = round_up_sz(woff, 256);
+    c.w_off = woff;
+    woff += c.w_bytes;
+    woff = round_up_sz(woff, 256);
+    c.b_off = woff;
+    woff += (size_t)c.CoutP * sizeof(float);
+  }
+  e->weights_bytes = round_up_sz(woff, 256);
+  // dominant conv step for the roofline probe: the first paired 7x7 step whose input is not a concat
+  e->dominant_step = -1;
+  for (size_t si = 0; si < e->steps.size(); ++si) {
+    const Step& s = e->steps[si];
+    if (s.type == 1 && e->convs[s.a].k == 7 && e->convs[s.a].cin == 128) { e->dominant_step = (int)si; break; }
+  }
+  e->strip_rows = 8;
+  e->nstrips = (e->cfg.net_h + e->strip_rows - 1) / e->strip_rows;
+  e->max_rows = e->num_limbs * e->max_peaks;
+  {
+    const size_t lds2 = (size_t)e->max_rows * (sizeof(double) + sizeof(int) + sizeof(int) * e->num_parts);
+    const size_t lds1 = (size_t)e->max_peaks * e->max_peaks * 8;
+    if (lds2 > 150 * 1024 || lds1 > 150 * 1024) return fail(e, RTP_EINVAL, "max_peaks %d needs more LDS than a CU has", e->max_peaks);
+  }
+  return RTP_OK;
+}
+
+// ---- weight packing -------------------------------------------------------------------------
+template <typename T>
+void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w, const std::vector<float>& b,
+               std::vector<unsigned char>* out_w, std::vector<float>* out_b) {
+  const Tensor& ti = e->tensors[c.in_tensor];
+  const int per_chunk = c.rowb / (int)sizeof(T);
+  const int taps = c.k_eff * c.k_eff;
+  out_w->assign(c.w_bytes, 0);
+  T* pw = (T*)out_w->data();
+  // internal channel -> reference index
+  if (c.first) {
+    // internal channel j = (r*3+s)*3 + cc  <->  W[n][cc][r][s]
+    for (int n = 0; n < c.cout; ++n)
+      for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s)
+          for (int cc = 0; cc < 3; ++cc) {
+            const int j = (r * 3 + s) * 3 + cc;
+            const int chunk = j / per_chunk, kk = j % per_chunk;
+            pw[((size_t)(0 * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kk] = (T)w[((size_t)(n * 3 + cc) * 3 + r) * 3 + s];
+          }
+  } else {
+    for (int n = 0; n < c.cout; ++n)
+      for (int cr = 0; cr < c.cin; ++cr) {
+        const int ci = ti.chmap[cr];
+        const int chunk = ci / per_chunk, kk = ci % per_chunk;
+        for (int r = 0; r < c.k; ++r)
+          for (int s = 0; s < c.k; ++s) {
+            const int tap = r * c.k + s;
+            pw[((size_t)(tap * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kk] = (T)w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
+          }
+      }
+  }
+  out_b->assign(c.CoutP, 0.f);
+  for (int n = 0; n < c.cout; ++n) (*out_b)[n] = b[n];
+}
+
+int upload_conv_weights(rtp_engine* e, int i) {
+  const ConvOp& c = e->convs[i];
+  std::vector<unsigned char> pw;
+  std::vector<float> pb;
+  if (e->prec == 0) pack_conv<_Float16>(e, c, e->w_ref[i], e->b_ref[i], &pw, &pb);
+  else pack_conv<float>(e, c, e->w_ref[i], e->b_ref[i], &pw, &pb);
+  HIPCHK(e, hipMemcpy(e->dweights + c.w_off, pw.data(), pw.size(), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(e->dweights + c.b_off, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
+  return RTP_OK;
+}
+
+// ---- launches -------------------------------------------------------------------------------
+void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProblem* pr) {
+  memset(pr, 0, sizeof(*pr));
+  pr->in = cx.arena + e->tensors[c.in_tensor].offset;
+  pr->w = e->dweights + c.w_off;
+  pr->bias = (const float*)(e->dweights + c.b_off);
+  pr->ndst = (int)c.dsts.size();
+  for (int d = 0; d < pr->ndst; ++d) {
+    const Tensor& t = e->tensors[c.dsts[d].first];
+    pr->dst[d].base = cx.arena + t.offset;
+    pr->dst[d].cstride = t.Cp;
+    pr->dst[d].coff = c.dsts[d].second;
+  }
+  if (c.to_lowres) {
+    pr->out_nchw = cx.lowres;
+    pr->out_C = e->heat_channels;
+    pr->out_coff = c.lowres_coff;
+  }
+  pr->Cout = c.cout;
+}
+
+int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
+  const ConvOp& A = e->convs[s.a];
+  const Geom& g = e->geom[A.level];
+  ConvParams P;
+  memset(&P, 0, sizeof P);
+  fill_problem(e, cx, A, &P.prob[0]);
+  if (s.b >= 0) fill_problem(e, cx, e->convs[s.b], &P.prob[1]);
+  P.H = g.H; P.W = g.W; P.Wp = g.Wp; P.halo = g.halo; P.img_pix = g.img_pix;
+  P.in_cstride = e->tensors[A.in_tensor].Cp;
+  P.nchunk = A.nchunk;
+  P.CoutP = A.CoutP;
+  const ConvCfgInfo ci = conv_cfg_info(A.cfg);
+  P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
+  P.relu = A.relu ? 1 : 0;
+  HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
+  return RTP_OK;
+}
+
+}  // namespace
+
+namespace {
+int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev) {
+  const std::vector<PoolOp>& pools = e->pools;
+  for (auto& s : e->steps) {
+    if (s.type == 0) {
+      const Tensor& t = e->tensors[0];
+      HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, e->geom[0], t.Cp, cx.stream));
+    } else if (s.type == 1) {
+      const int rc = launch_conv_step(e, cx, s);
+      if (rc) return rc;
+    } else {
+      const PoolOp& p = pools[s.a];
+      const Tensor& ti = e->tensors[p.in_tensor];
+      const Tensor& to = e->tensors[p.out_tensor];
+      HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, e->geom[ti.level], ti.Cp, cx.arena + to.offset, e->geom[to.level], to.Cp,
+                               round_up(p.C, 16 / e->elem), cx.stream));
+    }
+  }
+  return RTP_OK;
+}
+
+int run_resize(rtp_engine* e, Ctx& cx) {
+  ResizeParams rp;
+  rp.src = cx.lowres; rp.dst = cx.resized; rp.num = e->N; rp.C = e->heat_channels;
+  rp.h = e->low_h; rp.w = e->low_w; rp.tw = e->cfg.net_w; rp.th = e->cfg.net_h;
+  rp.start_scale = e->start_scale; rp.scale_gap = e->scale_gap;
+  HIPCHK(e, launch_resize(rp, cx.stream));
+  return RTP_OK;
+}
+int run_nms(rtp_engine* e, Ctx& cx) {
+  NmsParams np;
+  np.src = cx.resized; np.peaks = cx.peaks; np.strip_count = cx.strip_count; np.strip_list = cx.strip_list;
+  np.src_planes = e->heat_channels; np.H = e->cfg.net_h; np.W = e->cfg.net_w; np.num_parts = e->num_parts;
+  np.max_peaks = e->max_peaks; np.nstrips = e->nstrips; np.strip_rows = e->strip_rows; np.threshold = e->nms_threshold;
+  HIPCHK(e, launch_nms(np, cx.stream));
+  return RTP_OK;
+}
+int run_connect(rtp_engine* e, Ctx& cx) {
+  ConnectParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.heat = cx.resized; cp.peaks = cx.peaks; cp.joints = cx.joints; cp.num_people = cx.num_people;
+  cp.cand_score = cx.cand_score; cp.cand_ij = cx.cand_ij; cp.cand_count = cx.cand_count;
+  cp.conn = cx.conn; cp.conn_score = cx.conn_score; cp.conn_count = cx.conn_count;
+  cp.max_rows = e->max_rows; cp.model = e->model; cp.num_parts = e->num_parts; cp.num_limbs = e->num_limbs;
+  cp.max_peaks = e->max_peaks; cp.net_w = e->cfg.net_w; cp.net_h = e->cfg.net_h; cp.disp_w = e->cfg.disp_w; cp.disp_h = e->cfg.disp_h;
+  cp.inter_threshold = e->inter_threshold; cp.inter_min_above = e->inter_min_above; cp.min_subset_cnt = e->min_subset_cnt;
+  cp.min_subset_score = e->min_subset_score; cp.max_people = RTP_MAX_PEOPLE;
+  HIPCHK(e, launch_connect(cp, cx.stream));
+  return RTP_OK;
+}
+
+// whole frame on one context: conv stack -> resize -> nms -> connect -> D2H of joints
+int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev) {
+  int rc;
+  HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
+  if ((rc = run_frame_stack(e, cx, input_dev))) return rc;
+  HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
+  if ((rc = run_resize(e, cx))) return rc;
+  HIPCHK(e, hipEventRecord(cx.ev[2], cx.stream));
+  if ((rc = run_nms(e, cx))) return rc;
+  HIPCHK(e, hipEventRecord(cx.ev[3], cx.stream));
+  if ((rc = run_connect(e, cx))) return rc;
+  HIPCHK(e, hipEventRecord(cx.ev[4], cx.stream));
+  const size_t jbytes = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3 * sizeof(float);
+  HIPCHK(e, hipMemcpyAsync(cx.host_out + 4, cx.joints, jbytes, hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(e, hipMemcpyAsync(cx.host_out, cx.num_people, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+  HIPCHK(e, hipEventRecord(cx.ev[5], cx.stream));
+  return RTP_OK;
+}
+
+int alloc_ctx(rtp_engine* e, Ctx& cx) {
+  HIPCHK(e, hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
+  HIPCHK(e, hipMalloc((void**)&cx.arena, e->arena_bytes));
+  HIPCHK(e, hipMemset(cx.arena, 0, e->arena_bytes));
+  const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+  HIPCHK(e, hipMalloc((void**)&cx.input, in_floats * sizeof(float)));
+  HIPCHK(e, hipHostMalloc((void**)&cx.host_in, in_floats * sizeof(float), hipHostMallocDefault));
+  const size_t low_floats = (size_t)e->N * e->heat_channels * e->low_h * e->low_w;
+  HIPCHK(e, hipMalloc((void**)&cx.lowres, low_floats * sizeof(float)));
+  HIPCHK(e, hipMemset(cx.lowres, 0, low_floats * sizeof(float)));
+  const size_t res_floats = (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w;
+  HIPCHK(e, hipMalloc((void**)&cx.resized, res_floats * sizeof(float)));
+  const size_t peak_floats = (size_t)e->num_parts * (e->max_peaks + 1) * 3;
+  HIPCHK(e, hipMalloc((void**)&cx.peaks, peak_floats * sizeof(float)));
+  HIPCHK(e, hipMemset(cx.peaks, 0, peak_floats * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&cx.strip_count, (size_t)e->num_parts * e->nstrips * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&cx.strip_list, (size_t)e->num_parts * e->nstrips * e->max_peaks * sizeof(int)));
+  const size_t pairs = (size_t)e->num_limbs * e->max_peaks * e->max_peaks;
+  HIPCHK(e, hipMalloc((void**)&cx.cand_score, pairs * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&cx.cand_ij, pairs * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&cx.cand_count, e->num_limbs * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&cx.conn, (size_t)e->num_limbs * e->max_peaks * 2 * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&cx.conn_score, (size_t)e->num_limbs * e->max_peaks * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&cx.conn_count, e->num_limbs * sizeof(int)));
+  const size_t jfloats = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3;
+  HIPCHK(e, hipMalloc((void**)&cx.joints, jfloats * sizeof(float)));
+  HIPCHK(e, hipMemset(cx.joints, 0, jfloats * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&cx.num_people, sizeof(int)));
+  HIPCHK(e, hipHostMalloc((void**)&cx.host_out, (jfloats + 4) * sizeof(float), hipHostMallocDefault));
+  for (int i = 0; i < 6; ++i) HIPCHK(e, hipEventCreate(&cx.ev[i]));
+  return RTP_OK;
+}
+
+void free_ctx(Ctx& cx) {
+  if (cx.stream) (void)hipStreamSynchronize(cx.stream);
+  void* dptrs[] = {cx.arena, cx.input, cx.lowres, cx.resized, cx.peaks, cx.strip_count, cx.strip_list, cx.cand_score, cx.cand_ij,
+                   cx.cand_count, cx.conn, cx.conn_score, cx.conn_count, cx.joints, cx.num_people};
+  for (void* p : dptrs) if (p) (void)hipFree(p);
+  if (cx.host_in) (void)hipHostFree(cx.host_in);
+  if (cx.host_out) (void)hipHostFree(cx.host_out);
+  for (int i = 0; i < 6; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
+  if (cx.stream) (void)hipStreamDestroy(cx.stream);
+  cx = Ctx();
+}
+
+int use_device(rtp_engine* e) {
+  HIPCHK(e, hipSetDevice(e->cfg.device_id));
+  return RTP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int rtp_config_default(rtp_config* cfg) {
+  if (!cfg) return RTP_EINVAL;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->device_id = 0;
+  cfg->model = RTP_MODEL_COCO_18;
+  cfg->proto_path = nullptr;
+  cfg->weights_path = nullptr;
+  cfg->synthetic_seed = 1;
+  cfg->net_w = 656; cfg->net_h = 368;
+  cfg->num_scales = 1;
+  cfg->start_scale = 1.f; cfg->scale_gap = 0.3f;
+  cfg->disp_w = 1280; cfg->disp_h = 720;
+  cfg->precision = RTP_PREC_FP16;
+  cfg->frames_in_flight = 2;
+  return RTP_OK;
+}
+
+const char* rtp_version(void) { return "rtpose-mi355x 0.1 (gfx950)"; }
+
+const char* rtp_last_error(const rtp_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+void rtp_engine_destroy(rtp_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device_id);
+  for (auto& c : e->ctx) free_ctx(c);
+  if (e->dweights) (void)hipFree(e->dweights);
+  if (e->dchmap) (void)hipFree(e->dchmap);
+  delete e;
+}
+
+int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
+  if (!cfg || !out) return fail(nullptr, RTP_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->num_scales < 1 || cfg->num_scales > 16) return fail(nullptr, RTP_EINVAL, "num_scales %d out of range", cfg->num_scales);
+  if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 16) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
+  if (cfg->precision != RTP_PREC_FP16 && cfg->precision != RTP_PREC_FP32) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
+  if (cfg->disp_w < 1 || cfg->disp_h < 1) return fail(nullptr, RTP_EINVAL, "bad display resolution");
+  // CHECK_LE(target_width, NET_RESOLUTION_WIDTH) (rtpose.cpp:363): every scale must fit the net input
+  for (int i = 0; i < cfg->num_scales; ++i) {
+    const float s = cfg->start_scale - i * cfg->scale_gap;
+    if (!(s > 0.f) || 16 * std::ceil(cfg->net_w * s / 16) > cfg->net_w || 16 * std::ceil(cfg->net_h * s / 16) > cfg->net_h)
+      return fail(nullptr, RTP_EINVAL, "scale %d (%.3f) does not fit the net resolution", i, s);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, RTP_ENODEV, "no HIP device visible: this engine has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, RTP_ENODEV, "device %d not present (%d devices)", cfg->device_id, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) return fail(nullptr, RTP_ENODEV, "cannot query device %d", cfg->device_id);
+  if (!strstr(prop.gcnArchName, "gfx950")) return fail(nullptr, RTP_ENODEV, "device %d is %s; this engine is built for gfx950 (MI355X) only", cfg->device_id, prop.gcnArchName);
+
+  rtp_engine* e = new rtp_engine();
+  e->cfg = *cfg;
+  if (cfg->proto_path) { e->proto_path = cfg->proto_path; e->cfg.proto_path = e->proto_path.c_str(); }
+  if (cfg->weights_path) { e->weights_path = cfg->weights_path; e->cfg.weights_path = e->weights_path.c_str(); }
+  e->prec = cfg->precision;
+  e->elem = cfg->precision == RTP_PREC_FP16 ? 2 : 4;
+  e->N = cfg->num_scales;
+  e->start_scale = cfg->start_scale;
+  e->scale_gap = cfg->scale_gap;
+  auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
+
+  if (!e->proto_path.empty()) {
+    std::ifstream f(e->proto_path);
+    if (!f) return bail(fail(e, RTP_EIO, "cannot open prototxt %s", e->proto_path.c_str()));
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string perr;
+    if (!parse_prototxt(ss.str(), &e->net, &perr)) return bail(fail(e, RTP_EIO, "prototxt %s: %s", e->proto_path.c_str(), perr.c_str()));
+  } else {
+    if (cfg->model != RTP_MODEL_COCO_18 && cfg->model != RTP_MODEL_MPI_15) return bail(fail(e, RTP_EINVAL, "unknown model %d", cfg->model));
+    e->net = build_linevec(cfg->model);
+  }
+  int rc = build_plan(e);
+  if (rc) return bail(rc);
+  // thresholds as warmup() sets them (rtpose.cpp:212-226)
+  rtp_default_thresholds(e->model, &e->nms_threshold, &e->inter_threshold, &e->inter_min_above, &e->min_subset_cnt, &e->min_subset_score);
+
+  // weights
+  e->w_ref.resize(e->convs.size());
+  e->b_ref.resize(e->convs.size());
+  if (!e->weights_path.empty()) {
+    std::vector<LayerWeights> lw;
+    std::string werr;
+    if (!read_caffemodel(e->weights_path, &lw, &werr)) return bail(fail(e, RTP_EIO, "%s", werr.c_str()));
+    // CopyTrainedLayersFrom: match by layer name; unknown source layers ignored; shapes must match (net.cpp:750-786)
+    for (size_t i = 0; i < e->convs.size(); ++i) {
+      const ConvOp& c = e->convs[i];
+      const LayerWeights* src = nullptr;
+      for (auto& L : lw) if (L.name == c.name) src = &L;
+      if (!src) return bail(fail(e, RTP_EIO, "layer %s has no weights in %s", c.name.c_str(), e->weights_path.c_str()));
+      if (src->blobs.size() != 2 || src->blobs[0].data.size() != (size_t)c.cout * c.cin * c.k * c.k || src->blobs[1].data.size() != (size_t)c.cout)
+        return bail(fail(e, RTP_EIO, "Cannot copy param of layer '%s': shape mismatch", c.name.c_str()));
+      e->w_ref[i] = src->blobs[0].data;
+      e->b_ref[i] = src->blobs[1].data;
+    }
+  } else {
+    for (size_t i = 0; i < e->convs.size(); ++i) {
+      const ConvOp& c = e->convs[i];
+      synth_conv_weights(cfg->synthetic_seed, c.name, c.cout, c.cin, c.k, &e->w_ref[i], &e->b_ref[i]);
+    }
+  }
+
+  if ((rc = use_device(e))) return bail(rc);
+  {
+    hipError_t s = hipMalloc((void**)&e->dweights, e->weights_bytes);
+    if (s != hipSuccess) return bail(fail(e, RTP_ENOMEM, "hipMalloc(%zu) for weights failed: %s", e->weights_bytes, hipGetErrorString(s)));
+    s = hipMemset(e->dweights, 0, e->weights_bytes);
+    if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "hipMemset failed: %s", hipGetErrorString(s)));
+    s = hipMalloc((void**)&e->dchmap, 4096 * sizeof(int));
+    if (s != hipSuccess) return bail(fail(e, RTP_ENOMEM, "hipMalloc failed"));
+  }
+  for (size_t i = 0; i < e->convs.size(); ++i)
+    if ((rc = upload_conv_weights(e, (int)i))) return bail(rc);
+  e->ctx.resize(cfg->frames_in_flight);
+  for (auto& c : e->ctx)
+    if ((rc = alloc_ctx(e, c))) return bail(rc);
+  // dry run, as warmup() does (rtpose.cpp:233)
+  {
+    Ctx& cx = e->ctx[0];
+    const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+    hipError_t s = hipMemsetAsync(cx.input, 0, in_floats * sizeof(float), cx.stream);
+    if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "hipMemsetAsync failed"));
+    if ((rc = enqueue_frame(e, cx, cx.input))) return bail(rc);
+    s = hipStreamSynchronize(cx.stream);
+    if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s)));
+  }
+  *out = e;
+  return RTP_OK;
+}
+
+int rtp_engine_info(const rtp_engine* e, int* num_parts, int* max_peaks, int* heat_channels, int* low_w, int* low_h) {
+  if (!e) return RTP_EINVAL;
+  if (num_parts) *num_parts = e->num_parts;
+  if (max_peaks) *max_peaks = e->max_peaks;
+  if (heat_channels) *heat_channels = e->heat_channels;
+  if (low_w) *low_w = e->low_w;
+  if (low_h) *low_h = e->low_h;
+  return RTP_OK;
+}
+
+int rtp_set_thresholds(rtp_engine* e, float nms_threshold, float connect_inter_threshold, int connect_inter_min_above_threshold,
+                       int connect_min_subset_cnt, float connect_min_subset_score) {
+  if (!e) return RTP_EINVAL;
+  e->nms_threshold = nms_threshold;
+  e->inter_threshold = connect_inter_threshold;
+  e->inter_min_above = connect_inter_min_above_threshold;
+  e->min_subset_cnt = connect_min_subset_cnt;
+  e->min_subset_score = connect_min_subset_score;
+  return RTP_OK;
+}
+int rtp_get_thresholds(const rtp_engine* e, float* a, float* b, int* c, int* d, float* f) {
+  if (!e) return RTP_EINVAL;
+  if (a) *a = e->nms_threshold;
+  if (b) *b = e->inter_threshold;
+  if (c) *c = e->inter_min_above;
+  if (d) *d = e->min_subset_cnt;
+  if (f) *f = e->min_subset_score;
+  return RTP_OK;
+}
+int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap) {
+  if (!e) return RTP_EINVAL;
+  e->start_scale = start_scale;
+  e->scale_gap = scale_gap;
+  return RTP_OK;
+}
+
+static int pick_ctx(rtp_engine* e) {
+  for (size_t i = 0; i < e->ctx.size(); ++i)
+    if (!e->ctx[i].busy) return (int)i;
+  return -1;
+}
+
+int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
+  if (!e || !d_in) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  const int ci = pick_ctx(e);
+  if (ci < 0) return fail(e, RTP_EAGAIN, "all %zu frame contexts are busy", e->ctx.size());
+  Ctx& cx = e->ctx[ci];
+  if ((rc = enqueue_frame(e, cx, d_in))) return rc;
+  cx.tag = tag;
+  cx.busy = true;
+  e->fifo.push_back(ci);
+  return RTP_OK;
+}
+
+int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
+  if (!e || !h_in) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  const int ci = pick_ctx(e);
+  if (ci < 0) return fail(e, RTP_EAGAIN, "all %zu frame contexts are busy", e->ctx.size());
+  Ctx& cx = e->ctx[ci];
+  const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
+  memcpy(cx.host_in, h_in, bytes);
+  HIPCHK(e, hipMemcpyAsync(cx.input, cx.host_in, bytes, hipMemcpyHostToDevice, cx.stream));
+  if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
+  cx.tag = tag;
+  cx.busy = true;
+  e->fifo.push_back(ci);
+  return RTP_OK;
+}
+
+int rtp_in_flight(const rtp_engine* e) { return e ? (int)e->fifo.size() : 0; }
+
+int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) {
+  if (!e) return RTP_EINVAL;
+  if (e->fifo.empty()) return fail(e, RTP_EAGAIN, "nothing in flight");
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  const int ci = e->fifo.front();
+  Ctx& cx = e->ctx[ci];
+  HIPCHK(e, hipEventSynchronize(cx.ev[5]));
+  e->fifo.pop_front();
+  cx.busy = false;
+  int n;
+  memcpy(&n, cx.host_out, sizeof(int));
+  if (tag) *tag = cx.tag;
+  for (int i = 0; i < 5; ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, cx.ev[i == 4 ? 0 : i], cx.ev[i == 4 ? 5 : i + 1]);
+    e->last_ms[i] = ms;
+  }
+  if (n < 0) {
+    if (num_people) *num_people = 0;
+    return fail(e, RTP_ERANGE, "connect: a PAF sample coordinate fell outside the net resolution (the reference CHECK-fails here, rtpose.cpp:928)");
+  }
+  if (n > RTP_MAX_PEOPLE) n = RTP_MAX_PEOPLE;
+  if (num_people) *num_people = n;
+  if (joints) memcpy(joints, cx.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
+  return RTP_OK;
+}
+
+int rtp_last_stage_ms(const rtp_engine* e, float ms[5]) {
+  if (!e || !ms) return RTP_EINVAL;
+  memcpy(ms, e->last_ms, sizeof e->last_ms);
+  return RTP_OK;
+}
+
+// ---- synchronous taps (context 0; require an idle engine) ---------------------------------------
+static int need_idle(rtp_engine* e) {
+  if (!e) return RTP_EINVAL;
+  if (!e->fifo.empty()) return fail(e, RTP_EAGAIN, "parity taps need an idle engine (collect %zu frames first)", e->fifo.size());
+  return use_device(e);
+}
+
+int rtp_forward_debug(rtp_engine* e, const float* h_in, float* lowres, float* resized, float* peaks, float* joints, int* num_people) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!h_in) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
+  HIPCHK(e, hipMemcpy(cx.input, h_in, bytes, hipMemcpyHostToDevice));
+  if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
+  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  if (lowres) HIPCHK(e, hipMemcpy(lowres, cx.lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyDeviceToHost));
+  if (resized) HIPCHK(e, hipMemcpy(resized, cx.resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
+  if (peaks) HIPCHK(e, hipMemcpy(peaks, cx.peaks, (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  int n;
+  memcpy(&n, cx.host_out, sizeof(int));
+  for (int i = 0; i < 5; ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, cx.ev[i == 4 ? 0 : i], cx.ev[i == 4 ? 5 : i + 1]);
+    e->last_ms[i] = ms;
+  }
+  if (n < 0) { if (num_people) *num_people = 0; return fail(e, RTP_ERANGE, "connect: PAF sample coordinate out of range"); }
+  if (num_people) *num_people = n;
+  if (joints) memcpy(joints, cx.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
+  return RTP_OK;
+}
+
+int rtp_forward_heatmaps(rtp_engine* e, const float* h_in, float* lowres) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!h_in || !lowres) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
+  HIPCHK(e, hipMemcpy(cx.input, h_in, bytes, hipMemcpyHostToDevice));
+  if ((rc = run_frame_stack(e, cx, cx.input))) return rc;
+  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  HIPCHK(e, hipMemcpy(lowres, cx.lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
+int rtp_resize(rtp_engine* e, const float* lowres, float* resized) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!lowres || !resized) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  HIPCHK(e, hipMemcpy(cx.lowres, lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyHostToDevice));
+  if ((rc = run_resize(e, cx))) return rc;
+  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  HIPCHK(e, hipMemcpy(resized, cx.resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
+int rtp_nms(rtp_engine* e, const float* resized, float* peaks) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!resized || !peaks) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  const size_t pbytes = (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float);
+  HIPCHK(e, hipMemcpy(cx.resized, resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cx.peaks, peaks, pbytes, hipMemcpyHostToDevice));
+  if ((rc = run_nms(e, cx))) return rc;
+  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  HIPCHK(e, hipMemcpy(peaks, cx.peaks, pbytes, hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
+int rtp_connect(rtp_engine* e, const float* resized, const float* peaks, float* joints, int* num_people) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!resized || !peaks) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  HIPCHK(e, hipMemcpy(cx.resized, resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cx.peaks, peaks, (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float), hipMemcpyHostToDevice));
+  if ((rc = run_connect(e, cx))) return rc;
+  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  int n = 0;
+  HIPCHK(e, hipMemcpy(&n, cx.num_people, sizeof(int), hipMemcpyDeviceToHost));
+  if (n < 0) { if (num_people) *num_people = 0; return fail(e, RTP_ERANGE, "connect: PAF sample coordinate out of range"); }
+  if (num_people) *num_people = n;
+  if (joints && n > 0) HIPCHK(e, hipMemcpy(joints, cx.joints, (size_t)n * e->num_parts * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
+int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int shape[4]) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!name) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  if (e->lowres_blob == name) {
+    const size_t n = (size_t)e->N * e->heat_channels * e->low_h * e->low_w;
+    if (shape) { shape[0] = e->N; shape[1] = e->heat_channels; shape[2] = e->low_h; shape[3] = e->low_w; }
+    if (!out) return RTP_OK;
+    if (cap < n) return fail(e, RTP_EINVAL, "blob %s needs %zu floats", name, n);
+    HIPCHK(e, hipMemcpy(out, cx.lowres, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RTP_OK;
+  }
+  auto it = e->blob_tensor.find(name);
+  if (it == e->blob_tensor.end()) return fail(e, RTP_EINVAL, "Unknown blob name %s", name);  // net.cpp blob_by_name warning
+  const Tensor& t = e->tensors[it->second];
+  const Geom& g = e->geom[t.level];
+  const size_t n = (size_t)g.N * t.C * g.H * g.W;
+  if (shape) { shape[0] = g.N; shape[1] = t.C; shape[2] = g.H; shape[3] = g.W; }
+  if (!out) return RTP_OK;
+  if (cap < n) return fail(e, RTP_EINVAL, "blob %s needs %zu floats", name, n);
+  if (t.C > 4096) return fail(e, RTP_EINVAL, "blob too wide");
+  float* dtmp = nullptr;
+  HIPCHK(e, hipMalloc((void**)&dtmp, n * sizeof(float)));
+  hipError_t s = hipMemcpy(e->dchmap, t.chmap.data(), t.C * sizeof(int), hipMemcpyHostToDevice);
+  if (s == hipSuccess) s = launch_export(e->prec, cx.arena + t.offset, g, t.Cp, e->dchmap, t.C, dtmp, cx.stream);
+  if (s == hipSuccess) s = hipStreamSynchronize(cx.stream);
+  if (s == hipSuccess) s = hipMemcpy(out, dtmp, n * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(dtmp);
+  if (s != hipSuccess) return fail(e, RTP_EHIP, "export failed: %s", hipGetErrorString(s));
+  return RTP_OK;
+}
+
+// ---- weights / graph ---------------------------------------------------------------------------
+int rtp_num_conv_layers(const rtp_engine* e) { return e ? (int)e->convs.size() : RTP_EINVAL; }
+int rtp_conv_layer_info(const rtp_engine* e, int i, char* name, int name_len, int* cin, int* cout, int* k) {
+  if (!e || i < 0 || i >= (int)e->convs.size()) return RTP_EINVAL;
+  const ConvOp& c = e->convs[i];
+  if (name && name_len > 0) snprintf(name, name_len, "%s", c.name.c_str());
+  if (cin) *cin = c.cin;
+  if (cout) *cout = c.cout;
+  if (k) *k = c.k;
+  return RTP_OK;
+}
+int rtp_get_conv_weights(const rtp_engine* e, int i, float* w, float* b) {
+  if (!e || i < 0 || i >= (int)e->convs.size()) return RTP_EINVAL;
+  if (w) memcpy(w, e->w_ref[i].data(), e->w_ref[i].size() * sizeof(float));
+  if (b) memcpy(b, e->b_ref[i].data(), e->b_ref[i].size() * sizeof(float));
+  return RTP_OK;
+}
+int rtp_set_conv_weights(rtp_engine* e, int i, const float* w, const float* b) {
+  if (!e || i < 0 || i >= (int)e->convs.size() || !w || !b) return RTP_EINVAL;
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  e->w_ref[i].assign(w, w + e->w_ref[i].size());
+  e->b_ref[i].assign(b, b + e->b_ref[i].size());
+  HIPCHK(e, hipDeviceSynchronize());
+  return upload_conv_weights(e, i);
+}
+int rtp_save_caffemodel(const rtp_engine* e, const char* path) {
+  if (!e || !path) return RTP_EINVAL;
+  std::vector<LayerWeights> lw;
+  for (size_t i = 0; i < e->convs.size(); ++i) {
+    const ConvOp& c = e->convs[i];
+    LayerWeights L;
+    L.name = c.name; L.type = "Convolution";
+    BlobData w, b;
+    w.shape = {c.cout, c.cin, c.k, c.k};
+    w.data = e->w_ref[i];
+    b.shape = {c.cout};
+    b.data = e->b_ref[i];
+    L.blobs = {w, b};
+    lw.push_back(L);
+  }
+  std::string err;
+  if (!write_caffemodel(path, e->net.name, lw, &err)) return fail(const_cast<rtp_engine*>(e), RTP_EIO, "%s", err.c_str());
+  return RTP_OK;
+}
+int rtp_save_prototxt(const rtp_engine* e, const char* path) {
+  if (!e || !path) return RTP_EINVAL;
+  std::ofstream f(path);
+  if (!f) return fail(const_cast<rtp_engine*>(e), RTP_EIO, "cannot create %s", path);
+  f << emit_prototxt(e->net);
+  return f ? RTP_OK : RTP_EIO;
+}
+
+int rtp_prototxt_summary(const char* path, int* num_layers, int* num_conv, int* num_parts, int* max_peaks, float* nms_threshold,
+                         int* heat_channels) {
+  if (!path) return RTP_EINVAL;
+  std::ifstream f(path);
+  if (!f) return fail(nullptr, RTP_EIO, "cannot open %s", path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  NetDef n;
+  std::string err;
+  if (!parse_prototxt(ss.str(), &n, &err)) return fail(nullptr, RTP_EIO, "%s", err.c_str());
+  int nc = 0, np = 0, mp = 0, hc = 0;
+  float thr = 0;
+  std::map<std::string, int> ch;
+  for (auto& i : n.inputs) ch[i] = 3;
+  for (auto& L : n.layers) {
+    if (L.type == "Convolution") { ++nc; ch[L.tops[0]] = L.num_output; }
+    else if (L.type == "Pooling") ch[L.tops[0]] = ch[L.bottoms[0]];
+    else if (L.type == "Concat") { int c = 0; for (auto& b : L.bottoms) c += ch[b]; ch[L.tops[0]] = c; }
+    else if (L.type == "ImResize") hc = ch[L.bottoms[0]];
+    else if (L.type == "Nms") { np = L.num_parts; mp = L.max_peaks; thr = L.nms_threshold; }
+  }
+  if (num_layers) *num_layers = (int)n.layers.size();
+  if (num_conv) *num_conv = nc;
+  if (num_parts) *num_parts = np;
+  if (max_peaks) *max_peaks = mp;
+  if (nms_threshold) *nms_threshold = thr;
+  if (heat_channels) *heat_channels = hc;
+  return RTP_OK;
+}
+
+// ---- host-only weight utilities ------------------------------------------------------------------
+int rtp_synth_weights(uint64_t seed, const char* layer_name, int cout, int cin, int k, float* w, float* b) {
+  if (!layer_name || !w || !b || cout < 1 || cin < 1 || k < 1) return RTP_EINVAL;
+  std::vector<float> vw, vb;
+  synth_conv_weights(seed, layer_name, cout, cin, k, &vw, &vb);
+  memcpy(w, vw.data(), vw.size() * sizeof(float));
+  memcpy(b, vb.data(), vb.size() * sizeof(float));
+  return RTP_OK;
+}
+
+int rtp_write_synthetic_caffemodel(int model, uint64_t seed, const char* path) {
+  if (!path || (model != RTP_MODEL_COCO_18 && model != RTP_MODEL_MPI_15)) return RTP_EINVAL;
+  const NetDef net = build_linevec(model);
+  std::map<std::string, int> ch;
+  ch["image"] = 3;
+  std::vector<LayerWeights> lw;
+  for (auto& L : net.layers) {
+    if (L.type == "Convolution") {
+      const int cin = ch[L.bottoms[0]];
+      LayerWeights W;
+      W.name = L.name; W.type = "Convolution";
+      BlobData w, b;
+      synth_conv_weights(seed, L.name, L.num_output, cin, L.kernel, &w.data, &b.data);
+      w.shape = {L.num_output, cin, L.kernel, L.kernel};
+      b.shape = {L.num_output};
+      W.blobs = {w, b};
+      lw.push_back(W);
+      ch[L.tops[0]] = L.num_output;
+    } else if (L.type == "Pooling") ch[L.tops[0]] = ch[L.bottoms[0]];
+    else if (L.type == "Concat") { int c = 0; for (auto& bn : L.bottoms) c += ch[bn]; ch[L.tops[0]] = c; }
+  }
+  std::string err;
+  if (!write_caffemodel(path, net.name, lw, &err)) return fail(nullptr, RTP_EIO, "%s", err.c_str());
+  return RTP_OK;
+}
+
+int rtp_caffemodel_layer(const char* path, int index, char* name, int name_len, int* num_blobs, long* count0, long* count1,
+                         float* head0 /* first min(8,count0) floats of blob 0 */) {
+  if (!path) return RTP_EINVAL;
+  static thread_local std::string cached_path;
+  static thread_local std::vector<LayerWeights> cached;
+  if (cached_path != path) {
+    std::vector<LayerWeights> lw;
+    std::string err;
+    if (!read_caffemodel(path, &lw, &err)) return fail(nullptr, RTP_EIO, "%s", err.c_str());
+    cached.swap(lw);
+    cached_path = path;
+  }
+  if (index < 0) return (int)cached.size();
+  if (index >= (int)cached.size()) return RTP_EINVAL;
+  const LayerWeights& L = cached[index];
+  if (name && name_len > 0) snprintf(name, name_len, "%s", L.name.c_str());
+  if (num_blobs) *num_blobs = (int)L.blobs.size();
+  if (count0) *count0 = L.blobs.size() > 0 ? (long)L.blobs[0].data.size() : 0;
+  if (count1) *count1 = L.blobs.size() > 1 ? (long)L.blobs[1].data.size() : 0;
+  if (head0 && !L.blobs.empty())
+    for (size_t i = 0; i < 8 && i < L.blobs[0].data.size(); ++i) head0[i] = L.blobs[0].data[i];
+  return RTP_OK;
+}
+
+// Build the execution plan for cfg WITHOUT touching a device and describe it as text (tensors,
+// per-layer tile configuration, branch pairing, arena sizes).  Host logic only.
+long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
+  if (!cfg || !buf) return RTP_EINVAL;
+  rtp_engine* e = new rtp_engine();
+  e->cfg = *cfg;
+  e->prec = cfg->precision;
+  e->elem = cfg->precision == RTP_PREC_FP16 ? 2 : 4;
+  e->N = cfg->num_scales;
+  if (cfg->proto_path) {
+    std::ifstream f(cfg->proto_path);
+    std::stringstream ss;
+    std::string perr;
+    if (!f) { delete e; return fail(nullptr, RTP_EIO, "cannot open prototxt %s", cfg->proto_path); }
+    ss << f.rdbuf();
+    if (!parse_prototxt(ss.str(), &e->net, &perr)) { delete e; return fail(nullptr, RTP_EIO, "%s", perr.c_str()); }
+  } else e->net = build_linevec(cfg->model);
+  const int rc = build_plan(e);
+  if (rc) { g_create_error = e->err; delete e; return rc; }
+  std::ostringstream o;
+  o << "model " << e->model << " parts " << e->num_parts << " max_peaks " << e->max_peaks << " heat_channels " << e->heat_channels << "\n";
+  for (int l = 0; l < e->nlevels; ++l)
+    o << "level " << l << " H " << e->geom[l].H << " W " << e->geom[l].W << " halo " << e->geom[l].halo << "\n";
+  o << "arena_bytes " << e->arena_bytes << " weights_bytes " << e->weights_bytes << " tensors " << e->tensors.size() << "\n";
+  double gflop = 0;
+  for (auto& s : e->steps) {
+    if (s.type == 0) o << "step pack\n";
+    else if (s.type == 2) o << "step pool " << e->tensors[e->pools[s.a].in_tensor].name << " -> " << e->tensors[e->pools[s.a].out_tensor].name << "\n";
+    else {
+      const ConvOp& A = e->convs[s.a];
+      const ConvCfgInfo ci = conv_cfg_info(A.cfg);
+      const Geom& g = e->geom[A.level];
+      const long tiles = ((long)g.H * g.Wp + ci.BM - 1) / ci.BM;
+      o << "step conv " << A.name;
+      if (s.b >= 0) o << " + " << e->convs[s.b].name;
+      o << " k " << A.k << " cin_p " << A.Cin_p << " cout " << A.cout << " coutp " << A.CoutP << " relu " << A.relu << " tile " << ci.BM << "x" << ci.BN
+        << " rowb " << A.rowb << " wgs " << tiles * e->N * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
+      for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; gflop += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9; }
+    }
+  }
+  o << "conv_gflop " << gflop << "\n";
+  delete e;
+  const std::string str = o.str();
+  if (str.size() + 1 > buflen) return RTP_ERANGE;
+  memcpy(buf, str.c_str(), str.size() + 1);
+  return (long)str.size();
+}
+
+int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (e->dominant_step < 0 || iters < 1) return fail(e, RTP_EINVAL, "no 7x7 128->128 convolution step in this graph");
+  Ctx& cx = e->ctx[0];
+  const Step& s = e->steps[e->dominant_step];
+  const ConvOp& A = e->convs[s.a];
+  const Geom& g = e->geom[A.level];
+  for (int i = 0; i < 3; ++i) if ((rc = launch_conv_step(e, cx, s))) return rc;
+  HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
+  for (int i = 0; i < iters; ++i) if ((rc = launch_conv_step(e, cx, s))) return rc;
+  HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
+  HIPCHK(e, hipEventSynchronize(cx.ev[1]));
+  float ms = 0.f;
+  HIPCHK(e, hipEventElapsedTime(&ms, cx.ev[0], cx.ev[1]));
+  if (avg_ms) *avg_ms = ms / iters;
+  const int nprob = s.b >= 0 ? 2 : 1;
+  double fl = 0;
+  for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N; }
+  (void)nprob;
+  if (flops_per_launch) *flops_per_launch = fl;
+  return RTP_OK;
+}
+
+}  // extern "C"

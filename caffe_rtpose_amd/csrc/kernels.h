@@ -1,0 +1,125 @@
+// kernels.h — device-side contracts shared by the HIP kernels and the engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtp {
+
+// ---------------------------------------------------------------------------------------
+// Activation layout in HBM: NHWC with a zero spatial halo, one geometry per resolution level.
+//   element (n, y, x, c) lives at  base + ((n*Hp + y+halo)*Wp + x+halo)*Cp + c
+// Hp = H+2*halo, Wp = W+2*halo.  Halo pixels and pad channels are zeroed once at allocation
+// and never written, so a k x k convolution with pad <= halo needs no bounds test: tap (r,s)
+// of output pixel p (flat padded index) reads flat pixel p + (r-pad)*Wp + (s-pad).
+// ---------------------------------------------------------------------------------------
+struct Geom {
+  int N, H, W, halo, Hp, Wp;
+  long img_pix;  // Hp*Wp
+};
+
+#define RTP_MAX_DST 6
+struct ConvDst {
+  void* base;   // element pointer of (n=0, padded pixel 0, channel 0)
+  int cstride;  // channels per pixel (Cp) of the destination tensor
+  int coff;     // first channel this conv writes
+};
+
+struct ConvProblem {
+  const void* in;     // element pointer of (n=0, padded pixel 0, channel 0)
+  const void* w;      // packed weights [tap][chunk][CoutP][ROWB bytes]
+  const float* bias;  // [CoutP] fp32
+  ConvDst dst[RTP_MAX_DST];
+  int ndst;
+  float* out_nchw;  // optional fp32 planar output [N][out_C][H][W]
+  int out_C, out_coff;
+  int Cout;
+};
+
+struct ConvParams {
+  ConvProblem prob[2];  // blockIdx.z selects (the L1 / L2 branch pair shares every shape)
+  int H, W, Wp, halo;
+  long img_pix;
+  int in_cstride;  // channels per pixel of the input tensor
+  int nchunk;      // Cin_p*sizeof(T)/ROWB
+  int CoutP;       // Cout rounded up to a multiple of BN
+  int tiles_per_img;
+  int relu;
+};
+
+// which tile configuration a conv launch uses
+enum ConvCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_128x64 = 3, CFG_COUNT = 4 };
+
+struct ConvCfgInfo { int BM, BN; };
+inline ConvCfgInfo conv_cfg_info(int cfg) {
+  switch (cfg) {
+    case CFG_128x128: return {128, 128};
+    case CFG_64x128: return {64, 128};
+    case CFG_64x64: return {64, 64};
+    default: return {128, 64};
+  }
+}
+
+// prec: 0 = fp16 (MFMA f16, fp32 accumulate), 1 = fp32 (exact-f32 MFMA).  rowb: 64 or 128.
+// Returns hipSuccess or the launch error.
+hipError_t launch_conv(int prec, int cfg, int ks, int rowb, const ConvParams& P, int nprob, int N,
+                       hipStream_t stream);
+
+// NCHW fp32 [N][3][H][W] -> level-0 tensor with 32 channels = 3x3 im2col of the image
+// (channel (r*3+s)*3+c = in[c][y+r-1][x+s-1], zero outside; channels 27..31 zero).
+hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, int Cp, hipStream_t stream);
+// 2x2 stride-2 MAX pooling between two halo'd NHWC tensors (pooling_layer.cpp:140-180).
+hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C,
+                          hipStream_t stream);
+// halo'd NHWC (T) -> planar fp32 [N][C][H][W] (debug tap; channel map: out c reads in chmap[c]).
+hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, float* out,
+                         hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// Post-processing (bit-exact restatements of the reference's CUDA kernels / host loop).
+// ---------------------------------------------------------------------------------------
+struct ResizeParams {
+  const float* src;  // [num][C][h][w]
+  float* dst;        // [C][th][tw]
+  int num, C, h, w, tw, th;
+  float start_scale, scale_gap;
+};
+hipError_t launch_resize(const ResizeParams& p, hipStream_t stream);
+
+struct NmsParams {
+  const float* src;  // resized map [src_planes][H][W]
+  float* peaks;      // [num_parts][max_peaks+1][3]  (in/out)
+  int* strip_count;  // [num_parts][nstrips]
+  int* strip_list;   // [num_parts][nstrips][max_peaks]  flat pixel index of the first max_peaks maxima of the strip
+  int src_planes, H, W, num_parts, max_peaks, nstrips, strip_rows;
+  float threshold;
+};
+hipError_t launch_nms(const NmsParams& p, hipStream_t stream);
+
+struct ConnectParams {
+  const float* heat;   // resized map [C][net_h][net_w]
+  const float* peaks;  // [num_parts][max_peaks+1][3]
+  float* joints;       // [max_people][num_parts][3]
+  int* num_people;     // [1]  (<0: error code)
+  // scratch
+  float* cand_score;   // [num_limbs][max_peaks*max_peaks]
+  int* cand_ij;        // [num_limbs][max_peaks*max_peaks]  (i<<16|j), raster (i,j) order, compacted
+  int* cand_count;     // [num_limbs]
+  int* conn;           // [num_limbs][max_peaks][2]  (indexA, indexB) flat peak-score indices
+  float* conn_score;   // [num_limbs][max_peaks]
+  int* conn_count;     // [num_limbs]
+  int* subset_idx;     // [max_rows][num_parts]
+  double* subset_score;  // [max_rows]
+  int* subset_cnt;     // [max_rows]
+  int max_rows;
+  int model;           // 0 COCO_18, 1 MPI_15
+  int num_parts, num_limbs, max_peaks;
+  int net_w, net_h, disp_w, disp_h;
+  float inter_threshold;
+  int inter_min_above;
+  int min_subset_cnt;
+  float min_subset_score;
+  int max_people;
+};
+hipError_t launch_connect(const ConnectParams& p, hipStream_t stream);
+
+}  // namespace rtp

@@ -1,0 +1,462 @@
+// postproc.hip — ImResize, Nms and connectLimbs* as wavefront kernels, BIT-EXACT restatements.
+//
+// Compiled with -ffp-contract=off: every float/double operation below rounds exactly where the
+// reference's source rounds (no FMA fusion), so given the same low-res heat maps these kernels
+// reproduce the oracle's resized map, peak list and joints bit for bit.  f32 divide and sqrt are
+// correctly rounded on gfx950 under hipcc's default flags.
+//
+//   imresize_cubic_kernel    src/caffe/cpm/layers/imresize_layer.cu:9-18,99-155
+//   nms_register/scan/write  src/caffe/cpm/layers/nms_layer.cu:15-113,117-184
+//   connectLimbs(COCO)       examples/rtpose/rtpose.cpp:549-751, 808-1076
+//
+// Structure (MI355X-first, not the reference's launch pattern):
+//   resize : ONE launch over (x, y, c) instead of 57 per-channel launches.
+//   nms    : the reference does per part {flag kernel, thrust::exclusive_scan over 241k ints,
+//            write kernel} = 54 launches + 18 scans.  Here: strip kernel (8 image rows per
+//            workgroup; wave ballots + popcounts give each maximum its raster ordinal inside the
+//            strip, and only the first max_peaks pixel indices per strip are kept) and a write
+//            kernel that scans the <=46 strip totals and does the 7x7 centroid refine.  Raster
+//            order — which decides WHICH peaks survive the max_peaks cap — is preserved exactly.
+//   connect: score kernel (one workgroup per limb: PAF line integrals for all (i,j) pairs in
+//            raster order, ballot-compacted; then lane 0 runs the libstdc++-exact sort and the
+//            greedy assignment) and a single-wavefront assembly kernel that keeps the person
+//            table in LDS and parallelises the row searches over the 64 lanes.
+#include "kernels.h"
+#include "stdsort_replica.h"
+
+namespace rtp {
+
+// ---------------------------------------------------------------------------------------
+// ImResize
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic_interp(float v0, float v1, float v2, float v3, float dx) {
+  // imresize_layer.cu:14-17 with C++'s usual arithmetic conversions spelled out
+  const float t1 = (-0.5f * v0 + 1.5f * v1 - 1.5f * v2 + 0.5f * v3) * dx * dx * dx;
+  const double t2 = ((double)(v0 - 2.5f * v1) + 2.0 * (double)v2 - 0.5 * (double)v3) * (double)dx * (double)dx;
+  const float t3 = (-0.5f * v0 + 0.5f * v2) * dx;
+  return (float)((((double)t1 + t2) + (double)t3) + (double)v1);
+}
+
+__global__ __launch_bounds__(256) void resize_kernel(ResizeParams p) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int c = blockIdx.z;
+  if (x >= p.tw) return;
+  const long plane = (long)p.h * p.w;
+  const float* src_c = p.src + (long)c * plane;
+  const long src_offset = (long)p.C * plane;
+  float sum = 0.f;
+  for (int n = 0; n < p.num; ++n) {
+    const int padw = (int)floorf((float)(p.w / 2) * (1 - p.start_scale + n * p.scale_gap));
+    const int padh = (int)floorf((float)(p.h / 2) * (1 - p.start_scale + n * p.scale_gap));
+    const int ow = p.w - 2 * padw, oh = p.h - 2 * padh;
+    const float* sp = src_c + n * src_offset;
+    const float offset_x = (float)((double)(p.tw / (float)ow / 2) - 0.5);
+    const float offset_y = (float)((double)(p.th / (float)oh / 2) - 0.5);
+    const float x_on = (x - offset_x) * ((float)ow / p.tw);
+    const float y_on = (y - offset_y) * ((float)oh / p.th);
+    int xn0, xn1, xn2, xn3, yn[4];
+    xn1 = (int)((double)x_on + 1e-5);
+    xn1 = (xn1 < 0) ? 0 : xn1;
+    xn0 = ((xn1 - 1 < 0) ? xn1 : (xn1 - 1)) + padw;
+    xn2 = (xn1 + 1 >= ow) ? (ow - 1) : (xn1 + 1);
+    xn3 = ((xn2 + 1 >= ow) ? (ow - 1) : (xn2 + 1)) + padw;
+    const float dx = x_on - xn1;
+    xn1 += padw;
+    xn2 += padw;
+    yn[1] = (int)((double)y_on + 1e-5);
+    yn[1] = (yn[1] < 0) ? 0 : yn[1];
+    yn[0] = ((yn[1] - 1 < 0) ? yn[1] : (yn[1] - 1)) + padh;
+    yn[2] = (yn[1] + 1 >= oh) ? (oh - 1) : (yn[1] + 1);
+    yn[3] = ((yn[2] + 1 >= oh) ? (oh - 1) : (yn[2] + 1)) + padh;
+    const float dy = y_on - yn[1];
+    yn[1] += padh;
+    yn[2] += padh;
+    const int rw = ow + 2 * padw;
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      t[i] = cubic_interp(sp[yn[i] * rw + xn0], sp[yn[i] * rw + xn1], sp[yn[i] * rw + xn2], sp[yn[i] * rw + xn3], dx);
+    const float d = cubic_interp(t[0], t[1], t[2], t[3], dy);
+    sum = sum + d;
+  }
+  p.dst[((long)c * p.th + y) * p.tw + x] = sum / p.num;
+}
+
+hipError_t launch_resize(const ResizeParams& p, hipStream_t stream) {
+  dim3 grid((p.tw + 255) / 256, p.th, p.C);
+  hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// NMS
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int nms_flag(const float* s, int x, int y, int W, int H, float thr) {
+  // nms_register_kernel, nms_layer.cu:15-46
+  if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+    const float v = s[y * W + x];
+    if (v > thr) {
+      const float top = s[(y - 1) * W + x], bottom = s[(y + 1) * W + x];
+      const float left = s[y * W + x - 1], right = s[y * W + x + 1];
+      const float tl = s[(y - 1) * W + x - 1], tr = s[(y - 1) * W + x + 1];
+      const float bl = s[(y + 1) * W + x - 1], br = s[(y + 1) * W + x + 1];
+      if (v > top && v > bottom && v > left && v > right && v > tl && v > bl && v > br && v > tr) return 1;
+    }
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void nms_strip_kernel(NmsParams p) {
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int strip = blockIdx.x, part = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* s = p.src + (long)part * p.H * p.W;
+  const int y0 = strip * p.strip_rows;
+  const int y1 = min(y0 + p.strip_rows, p.H);
+  const int npix = (y1 - y0) * p.W;
+  const int pix0 = y0 * p.W;
+  int* list = p.strip_list + ((long)part * p.nstrips + strip) * p.max_peaks;
+  if (tid == 0) running = 0;
+  __syncthreads();
+  for (int base = 0; base < npix; base += 256) {
+    const int q = base + tid;
+    int f = 0;
+    if (q < npix) {
+      const int g = pix0 + q;
+      f = nms_flag(s, g % p.W, g / p.W, p.W, p.H, p.threshold);
+    }
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = running;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (f && ord < p.max_peaks) list[ord] = pix0 + q;
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) p.strip_count[part * p.nstrips + strip] = running;
+}
+
+__global__ __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
+  extern __shared__ int prefix[];  // [nstrips+1]
+  const int part = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < p.nstrips; ++i) {
+      prefix[i] = run;
+      run += p.strip_count[part * p.nstrips + i];
+    }
+    prefix[p.nstrips] = run;
+  }
+  __syncthreads();
+  const int total = prefix[p.nstrips];
+  const int W = p.W;
+  const long offset = (long)p.H * p.W;
+  const float* s = p.src + (long)part * offset;
+  float* dst = p.peaks + (long)part * (p.max_peaks + 1) * 3;
+  const int n = total < p.max_peaks ? total : p.max_peaks;
+  for (int e = tid; e < n; e += blockDim.x) {
+    int st = 0;
+    while (prefix[st + 1] <= e) ++st;  // strip holding ordinal e
+    const int g = p.strip_list[((long)part * p.nstrips + st) * p.max_peaks + (e - prefix[st])];
+    const int px = g % W, py = g / W;
+    // writeResultKernel, nms_layer.cu:70-105 (window bound on y is `width`; index 0 excluded)
+    float x_acc = 0.f, y_acc = 0.f, score_acc = 0.f;
+    for (int dy = -3; dy < 4; ++dy) {
+      if ((py + dy) > 0 && (py + dy) < W) {
+        for (int dx = -3; dx < 4; ++dx) {
+          if ((px + dx) > 0 && (px + dx) < W) {
+            const long idx = (long)(py + dy) * W + px + dx;
+            float score = 0.f;
+            if ((long)part * offset + idx < (long)p.src_planes * offset) score = s[idx];
+            const float fx = (float)(px + dx), fy = (float)(py + dy);
+            if (score > 0) {
+              x_acc += fx * score;
+              y_acc += fy * score;
+              score_acc += score;
+            }
+          }
+        }
+      }
+    }
+    const int oi = (e + 1) * 3;
+    dst[oi] = x_acc / score_acc;
+    dst[oi + 1] = y_acc / score_acc;
+    dst[oi + 2] = s[py * W + px];
+  }
+  if (tid == 0) dst[0] = (float)total;  // unclamped total, nms_layer.cu:110
+}
+
+hipError_t launch_nms(const NmsParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(nms_strip_kernel, dim3(p.nstrips, p.num_parts), dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(nms_write_kernel, dim3(p.num_parts), dim3(256), (p.nstrips + 1) * sizeof(int), stream, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// connectLimbs / connectLimbsCOCO
+// ---------------------------------------------------------------------------------------
+__constant__ int kCocoLimb[38] = {1, 2, 1, 5, 2, 3, 3, 4, 5, 6, 6, 7, 1, 8, 8, 9, 9, 10, 1, 11, 11, 12, 12, 13, 1, 0, 0, 14, 14, 16, 0, 15, 15, 17, 2, 16, 5, 17};
+__constant__ int kCocoMap[38] = {31, 32, 39, 40, 33, 34, 35, 36, 41, 42, 43, 44, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 47, 48, 49, 50, 53, 54, 51, 52, 55, 56, 37, 38, 45, 46};
+__constant__ int kMpiLimb[28] = {0, 1, 1, 2, 2, 3, 3, 4, 1, 5, 5, 6, 6, 7, 1, 14, 14, 11, 11, 12, 12, 13, 14, 8, 8, 9, 9, 10};
+__constant__ int kMpiMap[28] = {16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 38, 39, 40, 41, 42, 43, 32, 33, 34, 35, 36, 37};
+
+#define CONNECT_ERR_RANGE (-34)
+
+// One workgroup per limb k.  Phase 1: PAF line integral of every (i,j) candidate pair in the
+// reference's loop order (i outer, j inner; rtpose.cpp:897-951 / :611-651), survivors compacted
+// in that order.  Phase 2 (lane 0): std::sort-exact ordering + greedy assignment (:953-980).
+__global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  Cand* cands = (Cand*)lds_raw;  // [max_peaks*max_peaks]
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  __shared__ int err;
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool coco = p.model == 0;
+  const int* limbSeq = coco ? kCocoLimb : kMpiLimb;
+  const int* mapIdx = coco ? kCocoMap : kMpiMap;
+  const int NW = p.net_w, NH = p.net_h;
+  const int peaks_offset = 3 * (p.max_peaks + 1);
+  const float* map_x = p.heat + (long)mapIdx[2 * k] * NH * NW;
+  const float* map_y = p.heat + (long)mapIdx[2 * k + 1] * NH * NW;
+  const float* candA = p.peaks + limbSeq[2 * k] * peaks_offset;
+  const float* candB = p.peaks + limbSeq[2 * k + 1] * peaks_offset;
+  int nA = (int)candA[0], nB = (int)candB[0];
+  if (nA > p.max_peaks) nA = p.max_peaks;  // defined-behaviour clamp (see oracle NOTE)
+  if (nB > p.max_peaks) nB = p.max_peaks;
+  if (tid == 0) { running = 0; err = 0; }
+  __syncthreads();
+  if (nA == 0 || nB == 0) {
+    if (tid == 0) { p.cand_count[k] = 0; p.conn_count[k] = 0; }
+    return;
+  }
+  const int npairs = nA * nB;
+  const int num_inter = 10;
+  for (int base = 0; base < npairs; base += 256) {
+    const int q = base + tid;
+    int pass = 0;
+    float conn_score = 0.f;
+    int ij = 0;
+    if (q < npairs) {
+      const int i = q / nB + 1, j = q % nB + 1;
+      ij = (i << 16) | j;
+      const float s_x = candA[i * 3];
+      const float s_y = candA[i * 3 + 1];
+      const float d_x = candB[j * 3] - candA[i * 3];
+      const float d_y = candB[j * 3 + 1] - candA[i * 3 + 1];
+      float norm_vec;
+      if (coco) norm_vec = sqrtf(d_x * d_x + d_y * d_y);
+      else norm_vec = (float)sqrt((double)d_x * (double)d_x + (double)d_y * (double)d_y);  // pow(d,2) in double
+      if (!(norm_vec < 1e-6)) {
+        const float vec_x = d_x / norm_vec;
+        const float vec_y = d_y / norm_vec;
+        float sum = 0;
+        int count = 0;
+        bool bad = false;
+        for (int lm = 0; lm < num_inter; lm++) {
+          int my = (int)roundf(s_y + lm * d_y / num_inter);
+          int mx = (int)roundf(s_x + lm * d_x / num_inter);
+          if (coco) {
+            if (mx >= NW) mx = NW - 1;
+            if (my >= NH) my = NH - 1;
+          }
+          if (mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; break; }
+          const int idx = my * NW + mx;
+          const float score = (vec_x * map_x[idx] + vec_y * map_y[idx]);
+          if (score > p.inter_threshold) {
+            sum = sum + score;
+            count++;
+          }
+        }
+        if (bad) err = 1;
+        else if (count > p.inter_min_above) {
+          pass = 1;
+          conn_score = sum / count;
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = running;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pass) { cands[ord].score = conn_score; cands[ord].ij = ij; }
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  if (err) { *p.num_people = CONNECT_ERR_RANGE; }
+  const int nc = running;
+  p.cand_count[k] = nc;
+  std_sort_replica(cands, nc);
+  const int num = nA < nB ? nA : nB;
+  int cnt = 0;
+  unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};  // up to 256 peaks per part
+  int* conn = p.conn + (long)k * p.max_peaks * 2;
+  float* cs = p.conn_score + (long)k * p.max_peaks;
+  for (int row = 0; row < nc; ++row) {
+    if (cnt == num) break;
+    const int i = cands[row].ij >> 16, j = cands[row].ij & 0xffff;
+    const unsigned long long ba = 1ull << ((i - 1) & 63), bb = 1ull << ((j - 1) & 63);
+    if (!(occA[(i - 1) >> 6] & ba) && !(occB[(j - 1) >> 6] & bb)) {
+      conn[cnt * 2] = limbSeq[2 * k] * peaks_offset + i * 3 + 2;
+      conn[cnt * 2 + 1] = limbSeq[2 * k + 1] * peaks_offset + j * 3 + 2;
+      cs[cnt] = cands[row].score;
+      cnt++;
+      occA[(i - 1) >> 6] |= ba;
+      occB[(j - 1) >> 6] |= bb;
+    }
+  }
+  p.conn_count[k] = cnt;
+}
+
+// Person assembly (rtpose.cpp:982-1046 / :684-722) + emission (:1051-1073 / :726-748).
+// ONE wavefront; the subset table lives in LDS: idx[max_rows][num_parts] (flat index of the
+// part's score in the peaks array, 0 = absent), score[max_rows] (double), cnt[max_rows].
+__global__ __launch_bounds__(64) void connect_assemble_kernel(ConnectParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int NP = p.num_parts;
+  double* sscore = (double*)lds_raw;                       // [max_rows]
+  int* scnt = (int*)(sscore + p.max_rows);                 // [max_rows]
+  int* sidx = scnt + p.max_rows;                           // [max_rows][NP]
+  const int lane = threadIdx.x;
+  const bool coco = p.model == 0;
+  const int* limbSeq = coco ? kCocoLimb : kMpiLimb;
+  const int peaks_offset = 3 * (p.max_peaks + 1);
+  const float* peaks = p.peaks;
+  if (*p.num_people < 0) return;  // the score kernel flagged out-of-contract data
+  int nrows = 0;
+
+  auto append = [&](int partA, int idxA, int partB, int idxB, int cnt, double score) {
+    // all lanes call; lane 0 writes
+    if (nrows < p.max_rows) {
+      if (lane < NP) sidx[nrows * NP + lane] = 0;
+      __syncthreads();
+      if (lane == 0) {
+        sidx[nrows * NP + partA] = idxA;
+        if (partB >= 0) sidx[nrows * NP + partB] = idxB;
+        scnt[nrows] = cnt;
+        sscore[nrows] = score;
+      }
+      __syncthreads();
+      nrows++;
+    }
+  };
+
+  for (int k = 0; k < p.num_limbs; ++k) {
+    const int partA = limbSeq[2 * k], partB = limbSeq[2 * k + 1];
+    const float* candA = peaks + partA * peaks_offset;
+    const float* candB = peaks + partB * peaks_offset;
+    int nA = (int)candA[0], nB = (int)candB[0];
+    if (nA > p.max_peaks) nA = p.max_peaks;
+    if (nB > p.max_peaks) nB = p.max_peaks;
+    if (nA == 0 && nB == 0) continue;
+    if (nA == 0 || nB == 0) {
+      const int part = (nA == 0) ? partB : partA;
+      const float* cand = (nA == 0) ? candB : candA;
+      const int n = (nA == 0) ? nB : nA;
+      for (int i = 1; i <= n; ++i) {
+        const int off = part * peaks_offset + i * 3 + 2;
+        int found = 0;
+        if (coco) {  // rtpose.cpp:849-858, 873-881; the MPI version appends unconditionally
+          for (int j = lane; j < nrows; j += 64)
+            if (sidx[j * NP + part] == off) found = 1;
+          found = __any(found);
+        }
+        if (!found) append(part, off, -1, 0, 1, (double)cand[i * 3 + 2]);
+      }
+      continue;
+    }
+    const int nconn = p.conn_count[k];
+    const int* conn = p.conn + (long)k * p.max_peaks * 2;
+    const float* cs = p.conn_score + (long)k * p.max_peaks;
+    if (k == 0) {
+      for (int i = 0; i < nconn; ++i) {
+        const int indexA = conn[i * 2], indexB = conn[i * 2 + 1];
+        const double sc = (double)(peaks[indexA] + peaks[indexB]) + (double)cs[i];
+        append(partA, indexA, partB, indexB, 2, sc);
+      }
+    } else {
+      if (nconn == 0) continue;
+      for (int i = 0; i < nconn; ++i) {
+        const int indexA = conn[i * 2], indexB = conn[i * 2 + 1];
+        int num = 0;
+        for (int j = lane; j < nrows; j += 64) {
+          if (sidx[j * NP + partA] == indexA) {
+            sidx[j * NP + partB] = indexB;
+            num = 1;
+            scnt[j] = scnt[j] + 1;
+            sscore[j] = (sscore[j] + (double)peaks[indexB]) + (double)cs[i];
+          }
+        }
+        __syncthreads();
+        if (!__any(num)) {
+          const double sc = (double)(peaks[indexA] + peaks[indexB]) + (double)cs[i];
+          append(partA, indexA, partB, indexB, 2, sc);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // emit rows that pass the subset thresholds, in row order, at most max_people
+  int out = 0;
+  for (int base = 0; base < nrows && out < p.max_people; base += 64) {
+    const int j = base + lane;
+    int ok = 0;
+    if (j < nrows) {
+      const double c = (double)scnt[j];
+      ok = (c >= (double)p.min_subset_cnt) && ((sscore[j] / c) > (double)p.min_subset_score);
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int slot = out + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ok && slot < p.max_people) {
+      for (int q = 0; q < NP; ++q) {
+        const int idx = sidx[j * NP + q];
+        float* o = p.joints + ((long)slot * NP + q) * 3;
+        if (idx) {
+          o[2] = peaks[idx];
+          o[1] = peaks[idx - 1] * p.disp_h / (float)p.net_h;
+          o[0] = peaks[idx - 2] * p.disp_w / (float)p.net_w;
+        } else {
+          o[0] = 0; o[1] = 0; o[2] = 0;
+        }
+      }
+    }
+    out += __popcll(bal);
+  }
+  if (lane == 0) *p.num_people = out < p.max_people ? out : p.max_people;
+}
+
+hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  const size_t lds1 = (size_t)p.max_peaks * p.max_peaks * sizeof(Cand);
+  static bool attr1 = false, attr2 = false;
+  const size_t lds2 = (size_t)p.max_rows * (sizeof(double) + sizeof(int) + sizeof(int) * p.num_parts);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)attr1; (void)attr2;
+  e = hipFuncSetAttribute((const void*)connect_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)connect_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(connect_score_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(64), lds2, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace rtp

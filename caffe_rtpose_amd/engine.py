@@ -1,0 +1,277 @@
+"""ctypes mirror of include/rtpose_mi355x.h (numpy in / numpy out).  Plumbing only."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, rtp_config, fp, ip
+
+MODEL_COCO_18, MODEL_MPI_15 = 0, 1
+PREC_FP16, PREC_FP32 = 0, 1
+MAX_PEOPLE = 96
+
+
+class RtpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rtp error {code}: {msg}")
+        self.code = code
+
+
+def _f(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(fp)
+
+
+class Config:
+    def __init__(self, **kw):
+        self.c = rtp_config()
+        lib.rtp_config_default(C.byref(self.c))
+        self._keep = []
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, k, v):
+        if k in ("proto_path", "weights_path"):
+            v = None if v is None else str(v).encode()
+            self._keep.append(v)
+        setattr(self.c, k, v)
+        return self
+
+
+def model_tables(model):
+    npart, nlimb = C.c_int(), C.c_int()
+    limb = (C.c_int * 38)()
+    mp = (C.c_int * 38)()
+    rc = lib.rtp_model_tables(model, C.byref(npart), C.byref(nlimb), limb, mp)
+    if rc:
+        raise RtpError(rc, "bad model")
+    n = nlimb.value * 2
+    return npart.value, nlimb.value, list(limb)[:n], list(mp)[:n]
+
+
+def default_thresholds(model):
+    a, b, e = C.c_float(), C.c_float(), C.c_float()
+    c, d = C.c_int(), C.c_int()
+    rc = lib.rtp_default_thresholds(model, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e))
+    if rc:
+        raise RtpError(rc, "bad model")
+    return dict(nms_threshold=a.value, inter_threshold=b.value, inter_min_above=c.value, min_subset_cnt=d.value,
+                min_subset_score=e.value)
+
+
+def process_and_pad_image(img_u8, tw, th, normalize):
+    oh, ow, _ = img_u8.shape
+    out = np.empty((3, th, tw), np.float32)
+    img = np.ascontiguousarray(img_u8, np.uint8)
+    rc = lib.rtp_process_and_pad_image(_f(out), img.ctypes.data_as(C.POINTER(C.c_ubyte)), ow, oh, tw, th, int(normalize))
+    if rc:
+        raise RtpError(rc, "Image too big for target size.")
+    return out
+
+
+def format_json(joints, num_people, num_parts, frame_scale):
+    buf = C.create_string_buffer(1 << 20)
+    j = np.ascontiguousarray(joints, np.float32).reshape(-1)
+    if j.size == 0:
+        j = np.zeros(1, np.float32)
+    n = lib.rtp_format_json(buf, len(buf), _f(j), num_people, num_parts, C.c_float(frame_scale))
+    if n < 0:
+        raise RtpError(n, "format_json")
+    return buf.raw[:n]
+
+
+def prototxt_summary(path):
+    nl, nc, npart, mp, hc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    thr = C.c_float()
+    rc = lib.rtp_prototxt_summary(str(path).encode(), C.byref(nl), C.byref(nc), C.byref(npart), C.byref(mp), C.byref(thr), C.byref(hc))
+    if rc:
+        raise RtpError(rc, lib.rtp_last_error(None).decode())
+    return dict(num_layers=nl.value, num_conv=nc.value, num_parts=npart.value, max_peaks=mp.value,
+                nms_threshold=thr.value, heat_channels=hc.value)
+
+
+def synth_weights(seed, name, cout, cin, k):
+    w = np.empty((cout, cin, k, k), np.float32)
+    b = np.empty((cout,), np.float32)
+    rc = lib.rtp_synth_weights(seed, name.encode(), cout, cin, k, _f(w), _f(b))
+    if rc:
+        raise RtpError(rc, "synth_weights")
+    return w, b
+
+
+def write_synthetic_caffemodel(model, seed, path):
+    rc = lib.rtp_write_synthetic_caffemodel(model, seed, str(path).encode())
+    if rc:
+        raise RtpError(rc, lib.rtp_last_error(None).decode())
+
+
+def read_caffemodel_layers(path):
+    n = lib.rtp_caffemodel_layer(str(path).encode(), -1, None, 0, None, None, None, None)
+    if n < 0:
+        raise RtpError(n, lib.rtp_last_error(None).decode())
+    out = []
+    name = C.create_string_buffer(128)
+    nb = C.c_int()
+    c0, c1 = C.c_long(), C.c_long()
+    head = np.zeros(8, np.float32)
+    for i in range(n):
+        lib.rtp_caffemodel_layer(str(path).encode(), i, name, 128, C.byref(nb), C.byref(c0), C.byref(c1), _f(head))
+        out.append(dict(name=name.value.decode(), num_blobs=nb.value, count0=c0.value, count1=c1.value, head0=head.copy()))
+    return out
+
+
+def plan_summary(cfg):
+    buf = C.create_string_buffer(1 << 20)
+    n = lib.rtp_plan_summary(C.byref(cfg.c), buf, len(buf))
+    if n < 0:
+        raise RtpError(n, lib.rtp_last_error(None).decode())
+    return buf.raw[:n].decode()
+
+
+class Engine:
+    """One engine per GPU worker, like one caffe::Net per processFrame thread (rtpose.cpp:1463-1472)."""
+
+    def __init__(self, cfg=None, **kw):
+        self.cfg = cfg or Config(**kw)
+        self.h = C.c_void_p()
+        rc = lib.rtp_engine_create(C.byref(self.cfg.c), C.byref(self.h))
+        if rc:
+            self.h = C.c_void_p()
+            raise RtpError(rc, lib.rtp_last_error(None).decode())
+        a, b, c, d, e = (C.c_int() for _ in range(5))
+        lib.rtp_engine_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e))
+        self.num_parts, self.max_peaks, self.heat_channels, self.low_w, self.low_h = a.value, b.value, c.value, d.value, e.value
+        self.N = self.cfg.c.num_scales
+        self.net_w, self.net_h = self.cfg.c.net_w, self.cfg.c.net_h
+
+    def _chk(self, rc):
+        if rc:
+            raise RtpError(rc, lib.rtp_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            lib.rtp_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot loop
+    def submit(self, x, tag=0):
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.size == self.N * 3 * self.net_h * self.net_w
+        self._chk(lib.rtp_submit(self.h, _f(x), tag))
+
+    def submit_device(self, dptr, tag=0):
+        self._chk(lib.rtp_submit_device(self.h, C.c_void_p(dptr), tag))
+
+    def collect(self):
+        tag = C.c_uint64()
+        n = C.c_int()
+        joints = np.zeros((MAX_PEOPLE, self.num_parts, 3), np.float32)
+        self._chk(lib.rtp_collect(self.h, C.byref(tag), _f(joints), C.byref(n)))
+        return tag.value, n.value, joints[: n.value].copy()
+
+    def in_flight(self):
+        return lib.rtp_in_flight(self.h)
+
+    # ---- thresholds / scales
+    def set_thresholds(self, nms_threshold, inter_threshold, inter_min_above, min_subset_cnt, min_subset_score):
+        self._chk(lib.rtp_set_thresholds(self.h, nms_threshold, inter_threshold, inter_min_above, min_subset_cnt, min_subset_score))
+
+    def get_thresholds(self):
+        a, b, e = C.c_float(), C.c_float(), C.c_float()
+        c, d = C.c_int(), C.c_int()
+        self._chk(lib.rtp_get_thresholds(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        return dict(nms_threshold=a.value, inter_threshold=b.value, inter_min_above=c.value, min_subset_cnt=d.value,
+                    min_subset_score=e.value)
+
+    def set_scales(self, start_scale, scale_gap):
+        self._chk(lib.rtp_set_scales(self.h, start_scale, scale_gap))
+
+    # ---- parity taps
+    def forward_heatmaps(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty((self.N, self.heat_channels, self.low_h, self.low_w), np.float32)
+        self._chk(lib.rtp_forward_heatmaps(self.h, _f(x), _f(out)))
+        return out
+
+    def resize(self, lowres):
+        lowres = np.ascontiguousarray(lowres, np.float32)
+        assert lowres.shape == (self.N, self.heat_channels, self.low_h, self.low_w)
+        out = np.empty((self.heat_channels, self.net_h, self.net_w), np.float32)
+        self._chk(lib.rtp_resize(self.h, _f(lowres), _f(out)))
+        return out
+
+    def nms(self, resized, peaks_init=None):
+        resized = np.ascontiguousarray(resized, np.float32).reshape(self.heat_channels, self.net_h, self.net_w)
+        peaks = np.zeros((self.num_parts, self.max_peaks + 1, 3), np.float32) if peaks_init is None else np.ascontiguousarray(peaks_init, np.float32).copy()
+        self._chk(lib.rtp_nms(self.h, _f(resized), _f(peaks)))
+        return peaks
+
+    def connect(self, resized, peaks):
+        resized = np.ascontiguousarray(resized, np.float32).reshape(self.heat_channels, self.net_h, self.net_w)
+        peaks = np.ascontiguousarray(peaks, np.float32)
+        joints = np.zeros((MAX_PEOPLE, self.num_parts, 3), np.float32)
+        n = C.c_int()
+        self._chk(lib.rtp_connect(self.h, _f(resized), _f(peaks), _f(joints), C.byref(n)))
+        return n.value, joints
+
+    def forward_debug(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        lowres = np.empty((self.N, self.heat_channels, self.low_h, self.low_w), np.float32)
+        resized = np.empty((self.heat_channels, self.net_h, self.net_w), np.float32)
+        peaks = np.empty((self.num_parts, self.max_peaks + 1, 3), np.float32)
+        joints = np.zeros((MAX_PEOPLE, self.num_parts, 3), np.float32)
+        n = C.c_int()
+        self._chk(lib.rtp_forward_debug(self.h, _f(x), _f(lowres), _f(resized), _f(peaks), _f(joints), C.byref(n)))
+        return dict(lowres=lowres, resized=resized, peaks=peaks, joints=joints, num_people=n.value)
+
+    def get_blob(self, name):
+        shape = (C.c_int * 4)()
+        self._chk(lib.rtp_get_blob(self.h, name.encode(), None, 0, shape))
+        out = np.empty(tuple(shape), np.float32)
+        self._chk(lib.rtp_get_blob(self.h, name.encode(), _f(out), out.size, shape))
+        return out
+
+    # ---- weights
+    def conv_layers(self):
+        res = []
+        name = C.create_string_buffer(64)
+        cin, cout, k = C.c_int(), C.c_int(), C.c_int()
+        for i in range(lib.rtp_num_conv_layers(self.h)):
+            lib.rtp_conv_layer_info(self.h, i, name, 64, C.byref(cin), C.byref(cout), C.byref(k))
+            res.append((name.value.decode(), cin.value, cout.value, k.value))
+        return res
+
+    def get_conv_weights(self, i):
+        _, cin, cout, k = self.conv_layers()[i]
+        w = np.empty((cout, cin, k, k), np.float32)
+        b = np.empty((cout,), np.float32)
+        self._chk(lib.rtp_get_conv_weights(self.h, i, _f(w), _f(b)))
+        return w, b
+
+    def set_conv_weights(self, i, w, b):
+        w = np.ascontiguousarray(w, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        self._chk(lib.rtp_set_conv_weights(self.h, i, _f(w), _f(b)))
+
+    def save_caffemodel(self, path):
+        self._chk(lib.rtp_save_caffemodel(self.h, str(path).encode()))
+
+    def save_prototxt(self, path):
+        self._chk(lib.rtp_save_prototxt(self.h, str(path).encode()))
+
+    # ---- diagnostics
+    def last_stage_ms(self):
+        ms = (C.c_float * 5)()
+        lib.rtp_last_stage_ms(self.h, ms)
+        return dict(conv=ms[0], resize=ms[1], nms=ms[2], connect=ms[3], total=ms[4])
+
+    def bench_dominant_conv(self, iters=50):
+        ms = C.c_float()
+        fl = C.c_double()
+        self._chk(lib.rtp_bench_dominant_conv(self.h, iters, C.byref(ms), C.byref(fl)))
+        return ms.value, fl.value

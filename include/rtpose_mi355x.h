@@ -1,0 +1,187 @@
+/* rtpose_mi355x.h — C-ABI of the MI355X-native realtime multi-person pose engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of CMU's caffe_rtpose:
+ *   float NCHW net input -> VGG-19+CPM conv stack -> ImResize -> Nms -> connectLimbs* -> joints
+ * Every entry point names the reference interface it replaces (file:line relative to the
+ * reference tree).  The reference consumes that path through the Caffe Net API
+ * (examples/rtpose/rtpose.cpp:183-207, 1127-1166); a maintainer keeps rtpose.cpp's thread
+ * structure and swaps those calls for the ones below.
+ *
+ * Conventions
+ *   - plain C types only; caller owns every buffer it passes; all functions return 0 on
+ *     success or a negative RTP_E* code and NEVER abort (the reference's glog CHECK /
+ *     CUDA_CHECK abort the process, rtpose.cpp:208,247; common.hpp CUDA_CHECK).
+ *   - an engine is single-owner and not thread-safe: one engine per GPU worker thread,
+ *     exactly like one caffe::Net per processFrame thread (rtpose.cpp:1463-1472).
+ *   - host buffers may be pageable or pinned; "_device" variants take HIP device pointers.
+ *   - there is NO CPU fallback: without a gfx950 device rtp_engine_create fails with
+ *     RTP_ENODEV.
+ */
+#ifndef RTPOSE_MI355X_H_
+#define RTPOSE_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTP_OK 0
+#define RTP_EINVAL (-22)   /* bad argument / bad configuration                       */
+#define RTP_ENOMEM (-12)   /* host or device allocation failed                       */
+#define RTP_ENODEV (-19)   /* no usable gfx950 device                                */
+#define RTP_EIO (-5)       /* file could not be read / parsed                        */
+#define RTP_EAGAIN (-11)   /* submit queue full / nothing to collect                 */
+#define RTP_EHIP (-70)     /* a HIP runtime call failed (see rtp_last_error)         */
+#define RTP_ERANGE (-34)   /* out-of-contract data (e.g. sample coordinate < 0)      */
+
+#define RTP_MODEL_COCO_18 0 /* ModelDescriptorFactory::Type::COCO_18 (modelDescriptorFactory.cpp:30) */
+#define RTP_MODEL_MPI_15 1  /* ModelDescriptorFactory::Type::MPI_15  (modelDescriptorFactory.cpp:6)  */
+
+#define RTP_PREC_FP16 0 /* fp16 storage, MFMA f16 with fp32 accumulate (headline path)      */
+#define RTP_PREC_FP32 1 /* fp32 storage, exact-f32 MFMA (parity path, 1/16 the MFMA rate)   */
+
+#define RTP_MAX_PEOPLE 96    /* RENDER_MAX_PEOPLE, include/rtpose/renderFunctions.h:6 */
+#define RTP_MAX_NUM_PARTS 70 /* MAX_NUM_PARTS, rtpose.cpp:91                          */
+
+typedef struct rtp_engine rtp_engine;
+
+/* Replaces: flags + warmup() state (rtpose.cpp:50-72, 173-237). */
+typedef struct rtp_config {
+  int device_id;           /* --start_device + worker index (rtpose.cpp:1466)                     */
+  int model;               /* RTP_MODEL_*; ignored when proto_path is given                        */
+  const char* proto_path;  /* --caffeproto deploy prototxt, or NULL = built-in linevec net         */
+  const char* weights_path;/* --caffemodel binary NetParameter, or NULL = synthetic (seed below)   */
+  uint64_t synthetic_seed; /* deterministic He-scaled weights when weights_path == NULL            */
+  int net_w, net_h;        /* --net_resolution, multiples of 16 (rtpose.cpp:65)                    */
+  int num_scales;          /* --num_scales = blob N (rtpose.cpp:188, 1719)                          */
+  float start_scale;       /* --start_scale -> ImResizeLayer::SetStartScale (rtpose.cpp:201)       */
+  float scale_gap;         /* --scale_gap   -> ImResizeLayer::SetScaleGap   (rtpose.cpp:202)       */
+  int disp_w, disp_h;      /* --resolution: joints are returned in display coordinates (:1061)     */
+  int precision;           /* RTP_PREC_*                                                            */
+  int frames_in_flight;    /* >=1: independent frame contexts (stream + activations) per engine    */
+} rtp_config;
+
+/* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
+ * start_scale 1, scale_gap 0.3, 1280x720, fp16, 2 frames in flight. */
+int rtp_config_default(rtp_config* cfg);
+
+/* Replaces: new Net<float>(proto, TEST) + CopyTrainedLayersFrom + Reshape + dry run
+ * (rtpose.cpp:183-191, 233; net.cpp:49, 750-803). */
+int rtp_engine_create(const rtp_config* cfg, rtp_engine** out);
+void rtp_engine_destroy(rtp_engine* e);
+
+/* Replaces: NmsLayer::GetNumParts/GetMaxPeaks (nms_layer.hpp:11-44, rtpose.cpp:194-207) and
+ * the resized_map blob shape.  heat_channels = channels of concat_stage7 (57 COCO / 44 MPI). */
+int rtp_engine_info(const rtp_engine* e, int* num_parts, int* max_peaks, int* heat_channels,
+                    int* low_w, int* low_h);
+
+/* Replaces: the global.* thresholds written by warmup() and the UI thread
+ * (rtpose.cpp:212-226) and NmsLayer::SetThreshold (rtpose.cpp:1145). */
+int rtp_set_thresholds(rtp_engine* e, float nms_threshold, float connect_inter_threshold,
+                       int connect_inter_min_above_threshold, int connect_min_subset_cnt,
+                       float connect_min_subset_score);
+int rtp_get_thresholds(const rtp_engine* e, float* nms_threshold, float* connect_inter_threshold,
+                       int* connect_inter_min_above_threshold, int* connect_min_subset_cnt,
+                       float* connect_min_subset_score);
+
+/* Replaces: ImResizeLayer::SetStartScale/SetScaleGap (imresize_layer.hpp:11-45). */
+int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap);
+
+/* ---- the per-frame hot loop (rtpose.cpp:1127-1166) ---------------------------------- */
+
+/* Replaces: cudaMemcpy H2D into blobs()[0]->mutable_gpu_data() + ForwardFrom(0) + the
+ * heatmap/peaks read-back + connectLimbs*().  Asynchronous: returns once the frame is
+ * enqueued on one of the engine's frame contexts.  nchw_input: num_scales x 3 x net_h x net_w
+ * floats, the output of process_and_pad_image (rtpose.cpp:239-269).  RTP_EAGAIN when all
+ * frames_in_flight contexts are busy (collect first). */
+int rtp_submit(rtp_engine* e, const float* nchw_input_host, uint64_t tag);
+int rtp_submit_device(rtp_engine* e, const float* nchw_input_device, uint64_t tag);
+
+/* Blocks until the OLDEST submitted frame is finished; returns its tag, the number of people
+ * (<= RTP_MAX_PEOPLE) and joints[num_people][num_parts][3] = (x, y, score) in display
+ * coordinates — the array connectLimbs*() fills (rtpose.cpp:1051-1073).  joints must hold
+ * RTP_MAX_PEOPLE*num_parts*3 floats.  RTP_EAGAIN if nothing is in flight. */
+int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people);
+
+/* Number of frames submitted and not yet collected. */
+int rtp_in_flight(const rtp_engine* e);
+
+/* ---- parity taps (the Net::blob_by_name surface rtpose.cpp uses, :1093-1094, 1149-1150) - */
+
+/* Run the conv stack only; lowres receives concat_stage7 as num_scales x C x h x w fp32. */
+int rtp_forward_heatmaps(rtp_engine* e, const float* nchw_input_host, float* lowres_host);
+/* ImResizeLayer::Forward_gpu on caller data: lowres (num_scales x C x h x w) -> resized (C x net_h x net_w). */
+int rtp_resize(rtp_engine* e, const float* lowres_host, float* resized_host);
+/* NmsLayer::Forward_gpu on caller data: resized (C x H x W) -> peaks (num_parts x (max_peaks+1) x 3).
+ * peaks is IN/OUT: slots the kernel does not write keep the caller's contents. */
+int rtp_nms(rtp_engine* e, const float* resized_host, float* peaks_host);
+/* connectLimbs / connectLimbsCOCO on caller data -> joints, *num_people. */
+int rtp_connect(rtp_engine* e, const float* resized_host, const float* peaks_host, float* joints,
+                int* num_people);
+/* Full synchronous frame with every intermediate returned (any pointer may be NULL). */
+int rtp_forward_debug(rtp_engine* e, const float* nchw_input_host, float* lowres_host,
+                      float* resized_host, float* peaks_host, float* joints, int* num_people);
+/* Net::blob_by_name(name)->cpu_data() for any conv-stack blob of the LAST synchronous forward
+ * (rtp_forward_heatmaps / rtp_forward_debug), as N x C x H x W fp32.  shape[4] out. */
+int rtp_get_blob(rtp_engine* e, const char* name, float* out_host, size_t out_capacity_floats,
+                 int shape[4]);
+
+/* ---- weights / graph (net.cpp:750-803, caffe.proto:6-22,64-95,310-330) ------------------ */
+int rtp_num_conv_layers(const rtp_engine* e);
+int rtp_conv_layer_info(const rtp_engine* e, int i, char* name, int name_len, int* cin, int* cout, int* k);
+/* Weights in Caffe blob order: w[cout][cin][k][k], b[cout] (base_conv_layer.cpp:135-175). */
+int rtp_get_conv_weights(const rtp_engine* e, int i, float* w, float* b);
+int rtp_set_conv_weights(rtp_engine* e, int i, const float* w, const float* b);
+/* Serialise the current weights as a binary caffe NetParameter (.caffemodel). */
+int rtp_save_caffemodel(const rtp_engine* e, const char* path);
+/* Emit the engine's layer graph as deploy-prototxt text. */
+int rtp_save_prototxt(const rtp_engine* e, const char* path);
+
+/* ---- host-side pieces of the path (no GPU needed) ---------------------------------------- */
+/* ModelDescriptor tables (modelDescriptorFactory.cpp:25-26,52-53). limb_seq/map_idx: 2*num_limbs ints. */
+int rtp_model_tables(int model, int* num_parts, int* num_limbs, int* limb_seq, int* map_idx);
+/* Default thresholds chosen by warmup() (rtpose.cpp:212-226). */
+int rtp_default_thresholds(int model, float* nms_threshold, float* connect_inter_threshold,
+                           int* connect_inter_min_above_threshold, int* connect_min_subset_cnt,
+                           float* connect_min_subset_score);
+/* process_and_pad_image (rtpose.cpp:239-269): uint8 BGR HWC -> float planar, centre zero-pad. */
+int rtp_process_and_pad_image(float* target, const unsigned char* bgr, int ow, int oh, int tw, int th,
+                              int normalize);
+/* JSON body exactly as displayFrame writes it (rtpose.cpp:1394-1415). Returns bytes written
+ * (excluding the NUL) or RTP_ERANGE if buf is too small. frame_scale = Frame::scale. */
+long rtp_format_json(char* buf, size_t buflen, const float* joints, int num_people, int num_parts,
+                     float frame_scale);
+/* Parse a deploy prototxt and report the graph it describes (for tests / tools). */
+int rtp_prototxt_summary(const char* path, int* num_layers, int* num_conv, int* num_parts,
+                         int* max_peaks, float* nms_threshold, int* heat_channels);
+
+/* ---- diagnostics ------------------------------------------------------------------------- */
+const char* rtp_last_error(const rtp_engine* e); /* never NULL; also valid for e == NULL (create errors) */
+const char* rtp_version(void);
+/* Per-stage device time of the last collected frame, ms: [0]=conv stack [1]=resize [2]=nms
+ * [3]=connect [4]=total (the reference's "CNN time / Connect time" VLOGs, rtpose.cpp:1147,1168). */
+int rtp_last_stage_ms(const rtp_engine* e, float ms[5]);
+/* Time `iters` launches of the dominant conv kernel (Mconv 7x7 128->128 pair of stage 2) with
+ * HIP events on the engine's stream; returns avg ms per launch and the algorithmic FLOPs of one
+ * launch.  Used by bench.py for the roofline line. */
+int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch);
+
+/* Host-only weight utilities.  rtp_synth_weights: the deterministic generator behind
+ * synthetic_seed (w[cout][cin][k][k], b[cout]).  rtp_write_synthetic_caffemodel: the same weights
+ * for every conv of the built-in linevec net as a binary NetParameter.  rtp_caffemodel_layer:
+ * read a .caffemodel (new `layer` or V1 `layers`) — index < 0 returns the layer count. */
+int rtp_synth_weights(uint64_t seed, const char* layer_name, int cout, int cin, int k, float* w, float* b);
+int rtp_write_synthetic_caffemodel(int model, uint64_t seed, const char* path);
+int rtp_caffemodel_layer(const char* path, int index, char* name, int name_len, int* num_blobs,
+                         long* count0, long* count1, float* head0);
+
+/* Build the execution plan for cfg without touching a device and describe it as text (tile
+ * configuration per layer, L1/L2 pairing, arena sizes).  Returns bytes written or a negative code. */
+long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTPOSE_MI355X_H_ */
