@@ -54,6 +54,7 @@ struct ConvOp {
   int lowres_coff = 0;
   int level = 0;
   int Cin_p = 0, rowb = 128, nchunk = 1, CoutP = 0, cfg = 0;
+  int impl = 0;             // 0 = register-staged kernel (conv_igemm.hip), 1 = LDS-DMA ring (conv_ring.hip)
   size_t w_off = 0, b_off = 0, w_bytes = 0;
 };
 
@@ -381,11 +382,23 @@ int build_plan(rtp_engine* e) {
       if (!chosen && wg > best_wg) { best = cf; best_wg = wg; }
     }
     const ConvCfgInfo ci = conv_cfg_info(best);
+    const char* force = getenv("RTP_CONV_IMPL");
+    const bool allow_ring = !(force && !strcmp(force, "v1"));
     for (int idx : {s.a, s.b}) {
       if (idx < 0) continue;
       ConvOp& c = e->convs[idx];
       c.cfg = best;
       c.CoutP = round_up(maxcout, ci.BN);
+      c.impl = 0;
+      if (allow_ring && !c.first && (c.k_eff == 3 || c.k_eff == 7)) {
+        const int row_bytes = c.Cin_p * e->elem;
+        int chb = (best == CFG_64x64 && row_bytes % 256 == 0) ? 256 : 128;
+        if (row_bytes % chb == 0) {
+          c.impl = 1;
+          c.rowb = chb;
+          c.nchunk = row_bytes / chb;
+        }
+      }
     }
   }
 
@@ -439,6 +452,14 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
   const int taps = c.k_eff * c.k_eff;
   out_w->assign(c.w_bytes, 0);
   T* pw = (T*)out_w->data();
+  // element index of internal channel kk of output row n inside its rowb-byte row (ring kernels
+  // XOR the 16-byte chunk index with a function of the row, see conv_ring.hip)
+  auto kpos = [&](int n, int kk) {
+    if (c.impl == 0) return kk;
+    const int per16 = 16 / (int)sizeof(T);
+    const int c16 = kk / per16, within = kk % per16;
+    return ((c16 ^ conv_ring_swz(c.rowb, n)) * per16) + within;
+  };
   // internal channel -> reference index
   if (c.first) {
     // internal channel j = (r*3+s)*3 + cc  <->  W[n][cc][r][s]
@@ -448,7 +469,7 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
           for (int cc = 0; cc < 3; ++cc) {
             const int j = (r * 3 + s) * 3 + cc;
             const int chunk = j / per_chunk, kk = j % per_chunk;
-            pw[((size_t)(0 * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kk] = (T)w[((size_t)(n * 3 + cc) * 3 + r) * 3 + s];
+            pw[((size_t)(0 * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)w[((size_t)(n * 3 + cc) * 3 + r) * 3 + s];
           }
   } else {
     for (int n = 0; n < c.cout; ++n)
@@ -458,7 +479,7 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
         for (int r = 0; r < c.k; ++r)
           for (int s = 0; s < c.k; ++s) {
             const int tap = r * c.k + s;
-            pw[((size_t)(tap * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kk] = (T)w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
+            pw[((size_t)(tap * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
           }
       }
   }
@@ -512,7 +533,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
   P.relu = A.relu ? 1 : 0;
-  HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
+  if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
+  else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
   return RTP_OK;
 }
 
@@ -1184,7 +1206,7 @@ long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
       o << "step conv " << A.name;
       if (s.b >= 0) o << " + " << e->convs[s.b].name;
       o << " k " << A.k << " cin_p " << A.Cin_p << " cout " << A.cout << " coutp " << A.CoutP << " relu " << A.relu << " tile " << ci.BM << "x" << ci.BN
-        << " rowb " << A.rowb << " wgs " << tiles * e->N * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
+        << " rowb " << A.rowb << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->N * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
       for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; gflop += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9; }
     }
   }

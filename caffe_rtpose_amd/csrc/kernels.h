@@ -64,6 +64,12 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
 hipError_t launch_conv(int prec, int cfg, int ks, int rowb, const ConvParams& P, int nprob, int N,
                        hipStream_t stream);
 
+// LDS-DMA ring variant for k in {3,7}: chb = channel bytes per step (128, or 256 with the 64x64
+// tile); weights packed with the matching 16-byte-chunk swizzle (see conv_ring.hip).
+hipError_t launch_conv_ring(int prec, int cfg, int ks, int chb, const ConvParams& P, int nprob, int N,
+                            hipStream_t stream);
+inline int conv_ring_swz(int chb, int row) { return chb == 256 ? (row & 15) : ((row >> 1) & 7); }
+
 // NCHW fp32 [N][3][H][W] -> level-0 tensor with 32 channels = 3x3 im2col of the image
 // (channel (r*3+s)*3+c = in[c][y+r-1][x+s-1], zero outside; channels 27..31 zero).
 hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, int Cp, hipStream_t stream);
