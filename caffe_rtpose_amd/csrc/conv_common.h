@@ -27,6 +27,28 @@ template <> struct Mma<float> {
   }
 };
 
+// XCD-aware decode of a 1-D grid.  The dispatcher places workgroup `lin` on XCD lin % 8 and each
+// XCD has a private 4 MiB L2, so the grid is laid out such that one XCD sees a CONTIGUOUS range
+// of the logical index L = ((prob * ntiles + ntile) * mtiles_total + mtile): workgroups on one
+// XCD share one weight set (prob, ntile) and neighbouring pixel tiles, whose strips overlap.
+// (Placement affects speed only; the mapping is a bijection for any grid size.)
+struct BlockCoord { int prob, ntile, img, mtile; };
+__device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntiles, int total_m /* tiles_per_img*N */) {
+  const int total = gridDim.x;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, j = lin >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int L = P.xcdmap ? ((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j) : lin;
+  BlockCoord b;
+  const int mt = L % total_m;
+  const int rest = L / total_m;
+  b.ntile = rest % ntiles;
+  b.prob = rest / ntiles;
+  b.img = mt / P.tiles_per_img;
+  b.mtile = mt % P.tiles_per_img;
+  return b;
+}
+
 // Split-K reduction across the KSPLIT wave groups of a workgroup (through LDS, which must be
 // dead: callers barrier first) followed by bias + ReLU + convert + store of the interior pixels.
 // acc layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams P) {
   unsigned char* sA = smem;                     // 2 strips
   unsigned char* sB = smem + 2 * TR::A_BYTES;   // 2 weight tiles
 
-  const ConvProblem& pr = P.prob[blockIdx.z];
+  const BlockCoord bc = decode_block(P, P.CoutP / BN, P.tiles_per_img * P.nimg);
+  const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams P) {
   const int wn0 = (wrem % WN) * (BN / WN);
   const int lrow = lane & 31, lhalf = lane >> 5;
 
-  const int img = blockIdx.x / P.tiles_per_img;
-  const int m0 = (blockIdx.x % P.tiles_per_img) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int img = bc.img;
+  const int m0 = bc.mtile * BM;
+  const int n0 = bc.ntile * BN;
   const int nchunk = P.nchunk;
   const long pix_bytes = (long)P.in_cstride * (long)sizeof(T);
   // byte address of the strip origin for filter row 0 (pixel m0 shifted by (-PAD rows, -PAD cols))
@@ -211,7 +212,7 @@ static hipError_t launch_one(const ConvParams& P, int nprob, int N, hipStream_t 
     if (e != hipSuccess) return e;
     attr_mask.fetch_or(1u << (dev & 31), std::memory_order_relaxed);
   }
-  dim3 grid(P.tiles_per_img * N, P.CoutP / BN, nprob);
+  dim3 grid(P.tiles_per_img * N * (P.CoutP / BN) * nprob);
   hipLaunchKernelGGL(kern, grid, dim3(256), TR::LDS_BYTES, stream, P);
   return hipGetLastError();
 }

@@ -21,6 +21,8 @@
 // CHB = 128: chunk ^= (row >> 1) & 7 — either way the 16 rows of a ds_read_b128 lane group hit
 // 16 distinct 16-byte slots of the 256-byte bank row.
 #include <atomic>
+#include <cstdlib>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -30,12 +32,12 @@ template <int CHB> __device__ __host__ __forceinline__ int ring_swz(int row) {
   return CHB == 256 ? (row & 15) : ((row >> 1) & 7);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_>
 struct RingTraits {
   static constexpr int NCH = CHB / 16;
   static constexpr int G = CHB / 32;
   static constexpr int GPW = G / KSPLIT;
-  static constexpr int SB = 4;
+  static constexpr int SB = SB_;  // weight-tile ring stages (SB-1 taps in flight)
   static constexpr int RPI = 1024 / CHB;  // rows per DMA wave-instruction
   static constexpr int AROWS_RAW = BM + KS - 1;
   static constexpr int A_INSTR = ((AROWS_RAW + RPI - 1) / RPI + 3) / 4 * 4;
@@ -54,33 +56,105 @@ struct RingTraits {
   static_assert(G % KSPLIT == 0 && GPW >= 1, "k-groups split evenly");
   static_assert(B_INSTR % 4 == 0 && B_PW >= 1, "weight tile splits evenly over the waves");
   static_assert(KS == 3 || KS == 7, "strip reuse needs k > 1");
+  static_assert(SB >= 3 && (SB - 2) * B_PW + 2 * A_PW <= 63, "vmcnt is a 6-bit counter");
+  static_assert(2 * KS >= SB - 2, "at most two strips may be in flight (double-buffered strip)");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Counted VMEM wait + "all of this wave's LDS reads have RETURNED".  The second half matters: the
+// compiler is free to sink the MFMAs of a step (and the lgkmcnt wait in front of them) below the
+// next step's barrier, so without it a wave could pass the barrier with ds_reads of the stage that
+// another wave is about to overwrite by DMA still in flight (seen as run-to-run differences when
+// a co-resident workgroup keeps the LDS pipeline busy).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-// One LDS-DMA wave-instruction: 64 lanes x 16 bytes, lane l lands at LDS byte lds_wave_base + 16*l.
-// Issued from inline asm on purpose: hipcc cannot tell the ring stages apart, so with the builtin
-// it drains the whole DMA queue (s_waitcnt vmcnt(0)) before the first ds_read of every step.
-// Hidden in asm, the only VMEM waits in the main loop are the counted ones we place ourselves
-// (no other VMEM instruction is in flight there).  M0 carries the LDS base and is restored.
-__device__ __forceinline__ void dma16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
-  const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+// LDS-DMA groups.  Issued from inline asm on purpose: hipcc cannot tell the ring stages apart, so
+// with the builtin it drains the whole DMA queue (s_waitcnt vmcnt(0)) before the first ds_read of
+// every step.  Hidden in asm, the only VMEM waits in the main loop are the counted ones we place
+// ourselves (no other VMEM instruction is in flight there).  One group = NQ wave-instructions of
+// 64 lanes x 16 bytes: global address = sbase + voff + q*1024, LDS address = lds_addr + q*1024 +
+// 16*lane (the instruction offset applies to both sides).  M0 carries the LDS base; restored.
+template <int NQ>
+__device__ __forceinline__ void dma_group_same(const unsigned char* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_addr)
-      : "memory");
+  static_assert(NQ >= 1 && NQ <= 4, "13-bit instruction offset");
+  if constexpr (NQ == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  else if constexpr (NQ == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  else if constexpr (NQ == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+// per-instruction offsets: voff[q] must already have q*1024 subtracted
+template <int NQ>
+__device__ __forceinline__ void dma_group_each(const unsigned char* sbase, const unsigned* voff, unsigned lds_addr) {
+  unsigned keep;
+  static_assert(NQ >= 1 && NQ <= 4, "13-bit instruction offset");
+  if constexpr (NQ == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds_addr) : "memory");
+  else if constexpr (NQ == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, %4 offset:2048\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(sbase), "s"(lds_addr) : "memory");
+  else if constexpr (NQ == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(sbase), "s"(lds_addr) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[0]), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB>
+__device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
+// vmcnt to wait for at the top of step t (tap s of a strip): the number of DMA instructions this
+// wave may leave in flight.  Issue order inside a step: [strip of the NEXT filter row, if s == 0],
+// then the weight tile of step t+SB-1.
+//  (1) weight tile t was issued at step t-(SB-1).  Younger than it: the tiles of steps
+//      t-(SB-2)..t-1 and one strip for every such step u with s(u) == 0 (in the first strip of
+//      the kernel only steps u >= 0 exist).
+//  (2) at s == 0 the strip of THIS filter row is needed too; it was issued at step t-KS (or in
+//      the prologue, ahead of everything).  Younger than it: the KS weight tiles of steps
+//      t-KS..t-1.  For KS >= SB-1 condition (1) already implies (2).
+template <int KS, int SB, bool FIRST, int B_PW, int A_PW>
+constexpr int ring_wait_count(int s) {
+  int na = 0;
+  for (int d = 1; d <= SB - 2; ++d) {
+    if (FIRST && d > s) continue;
+    int sd = s - d;
+    while (sd < 0) sd += KS;
+    if (sd == 0) ++na;
+  }
+  int n = (SB - 2) * B_PW + na * A_PW;
+  if (s == 0 && !FIRST) {
+    const int n2 = KS * B_PW;
+    if (n2 < n) n = n2;
+  }
+  return n;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_>
 __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
-  using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB>;
+  using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
   constexpr int A_PW = TR::A_PW, B_PW = TR::B_PW, TM = TR::TM, TN = TR::TN;
   constexpr int PAD = KS / 2;
@@ -88,7 +162,8 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   unsigned char* sA = smem;
   unsigned char* sB = smem + 2 * TR::A_BYTES;
 
-  const ConvProblem& pr = P.prob[blockIdx.z];
+  const BlockCoord bc = decode_block(P, P.CoutP / BN, P.tiles_per_img * P.nimg);
+  const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,44 +173,45 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   const int wn0 = (wrem % WN) * (BN / WN);
   const int lrow = lane & 31, lhalf = lane >> 5;
 
-  const int img = blockIdx.x / P.tiles_per_img;
-  const int m0 = (blockIdx.x % P.tiles_per_img) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int img = bc.img;
+  const int m0 = bc.mtile * BM;
+  const int n0 = bc.ntile * BN;
   const int nchunk = P.nchunk;
   const long pix_bytes = (long)P.in_cstride * (long)sizeof(T);
-  const unsigned char* in_base = (const unsigned char*)pr.in +
+  // strip (r, chunk) starts at a_ptr; consecutive strips: chunk += 1 (CHB bytes), then next filter row
+  const unsigned char* a_ptr = (const unsigned char*)pr.in +
       ((long)img * P.img_pix + (long)P.halo * P.Wp + m0 - (long)PAD * P.Wp - PAD) * pix_bytes;
-  const unsigned char* w_base = (const unsigned char*)pr.w + (long)n0 * CHB;
-  const long w_chunk_stride = (long)P.CoutP * CHB;
-  const long w_tap_stride = (long)nchunk * w_chunk_stride;
   const long row_step_bytes = (long)P.Wp * pix_bytes;
+  // weights are packed in STEP order [r][chunk][s][CoutP][CHB]: the tile pointer just increments
+  const long w_tile_stride = (long)P.CoutP * CHB;
+  const unsigned char* b_ptr = (const unsigned char*)pr.w + (long)n0 * CHB;
 
-  // ---- per-lane DMA source offsets -------------------------------------------------------
-  // A strip: DMA instruction j covers rows [j*RPI, (j+1)*RPI); lane -> (row, physical chunk).
-  // This wave issues instructions j = wave*A_PW + q.
-  int a_src_off[A_PW];
+  // ---- per-lane DMA source offsets (loop invariant) ---------------------------------------
+  // A strip: DMA instruction j covers rows [j*RPI, (j+1)*RPI); lane -> (row, physical chunk); the
+  // source chunk is swizzled.  This wave issues instructions j = wave*A_PW + q; q*1024 is taken
+  // out because the instruction offset re-adds it on both the global and the LDS side.
+  unsigned a_voff[A_PW];
 #pragma unroll
   for (int q = 0; q < A_PW; ++q) {
     const int j = wave * A_PW + q;
     const int row = j * RPI + lane / NCH;
     const int cphys = lane % NCH;
-    a_src_off[q] = row * (int)pix_bytes + ((cphys ^ ring_swz<CHB>(row)) * 16);
+    a_voff[q] = (unsigned)(row * (int)pix_bytes + ((cphys ^ ring_swz<CHB>(row)) * 16) - (q & 3) * 1024);
   }
-  const int a_lds_off = wave * A_PW * 1024;  // + q*1024 (wave-uniform)
-  const int b_src_off = wave * B_PW * 1024 + lane * 16;  // + q*1024: packed weights are already swizzled
-  const int b_lds_off = wave * B_PW * 1024;
+  const unsigned b_voff = (unsigned)(wave * B_PW * 1024 + lane * 16);
+  const unsigned sA_addr = lds_addr_of(sA) + wave * A_PW * 1024;
+  const unsigned sB_addr = lds_addr_of(sB) + wave * B_PW * 1024;
 
-  auto issue_a = [&](int r, int chunk, int buf) {
-    const unsigned char* p = in_base + (long)r * row_step_bytes + (long)chunk * CHB;
-    unsigned char* l = sA + buf * TR::A_BYTES + a_lds_off;
-#pragma unroll
-    for (int q = 0; q < A_PW; ++q) dma16(p + a_src_off[q], l + q * 1024);
+  auto issue_a = [&](int buf) {  // strip at a_ptr -> sA[buf]
+    const unsigned l = sA_addr + buf * TR::A_BYTES;
+    if constexpr (A_PW <= 4) dma_group_each<A_PW>(a_ptr, a_voff, l);
+    else { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<A_PW - 4>(a_ptr, a_voff + 4, l + 4096); }
   };
-  auto issue_b = [&](int r, int chunk, int s, int stage) {
-    const unsigned char* p = w_base + (long)(r * KS + s) * w_tap_stride + (long)chunk * w_chunk_stride + b_src_off;
-    unsigned char* l = sB + stage * TR::B_BYTES + b_lds_off;
-#pragma unroll
-    for (int q = 0; q < B_PW; ++q) dma16(p + q * 1024, l + q * 1024);
+  auto issue_b = [&](int stage) {  // tile at b_ptr -> sB[stage]; advances b_ptr
+    const unsigned l = sB_addr + stage * TR::B_BYTES;
+    if constexpr (B_PW <= 4) dma_group_same<B_PW>(b_ptr, b_voff, l);
+    else { dma_group_same<4>(b_ptr, b_voff, l); dma_group_same<B_PW - 4>(b_ptr + 4096, b_voff, l + 4096); }
+    b_ptr += w_tile_stride;
   };
 
   floatx16 acc[TM][TN];
@@ -147,54 +223,41 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   const int nstrips = KS * nchunk;
-  const int T_steps = nstrips * KS;
 
-  // issue-side cursor: coordinates of the next weight tile to fetch (runs 3 steps ahead)
-  int ir = 0, ic = 0, is = 0, istep = 0;
-  auto issue_next_b = [&]() {
-    issue_b(ir, ic, is, istep & (SB - 1));
-    ++istep;
-    if (istep < T_steps) {  // past the end: keep re-issuing the last tile (dummy, keeps vmcnt uniform)
-      if (++is == KS) { is = 0; if (++ic == nchunk) { ic = 0; ++ir; } }
-    }
-  };
-
-  // ---- prologue: strip 0, weight tiles 0..2 ------------------------------------------------
-  issue_a(0, 0, 0);
-  issue_next_b();
-  issue_next_b();
-  issue_next_b();
+  // ---- prologue: strip 0, weight tiles 0..SB-2 ---------------------------------------------
+  issue_a(0);
+#pragma unroll
+  for (int i = 0; i < SB - 1; ++i) issue_b(i);
+  int ist = SB - 1;   // ring stage the next weight tile goes to
+  int st = 0;         // ring stage of the current step
+  int abuf = 0;
+  int chunk = 0;
 
   const int brow0 = wn0 + lrow;
   const int bswz = ring_swz<CHB>(brow0);
+  const unsigned char* pb_lane = sB + brow0 * CHB;
+  const int arow_base = wm0 + lrow;
 
-  int r = 0, chunk = 0, s = 0, abuf = 0;
-  for (int t = 0; t < T_steps; ++t) {
-    // Need: weight tile t (issued 3 steps ago) and, at s == 0, this strip (issued >= KS steps ago).
-    // Issued after tile t: tiles t+1, t+2 and possibly one A strip (if a step with s == 0 lies in
-    // [t-2, t-1], i.e. s is 1 or 2; a step issues its strip BEFORE its weight tile).
-    const bool a_recent = (t >= 1) && (s == 1 || s == 2);
-    if (a_recent) wait_vmcnt<2 * B_PW + A_PW>();
-    else wait_vmcnt<2 * B_PW>();
+  // one tap: wait for its weight tile (+strip), barrier, refill the ring, 2*GPW*... MFMAs
+  auto step = [&](auto s_tag, auto first_tag) {
+    constexpr int s = decltype(s_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-
-    // refill (strip FIRST, then the weight tile, so that the strip a step needs is always older
-    // than the weight tile it waits for): the buffers read in step t-1 are free now
-    if (s == 0) {
-      int nr = r, nc = chunk + 1;
-      if (nc == nchunk) { nc = 0; nr = r + 1; }
-      if (nr == KS) { nr = r; nc = chunk; }  // last strip: dummy reload of itself
-      issue_a(nr, nc, abuf ^ 1);
+    if constexpr (s == 0) {
+      // next strip (past the end: a harmless dummy read of arena memory keeps vmcnt uniform)
+      if (++chunk == nchunk) { chunk = 0; a_ptr += row_step_bytes - (long)(nchunk - 1) * CHB; }
+      else a_ptr += CHB;
+      issue_a(abuf ^ 1);
     }
-    issue_next_b();
-
-    // ---- MFMA on tile t -------------------------------------------------------------------
+    issue_b(ist);
+    ist = (ist + 1 == SB) ? 0 : ist + 1;
     {
-      const int arow = wm0 + lrow + s;
+      const int arow = arow_base + s;
       const int aswz = ring_swz<CHB>(arow);
       const unsigned char* pa = sA + abuf * TR::A_BYTES + arow * CHB;
-      const unsigned char* pb = sB + (t & (SB - 1)) * TR::B_BYTES + brow0 * CHB;
+      const unsigned char* pb = pb_lane + st * TR::B_BYTES;
 #pragma unroll
       for (int gi = 0; gi < GPW; ++gi) {
         const int cl = 2 * (kg * GPW + gi) + lhalf;
@@ -209,12 +272,24 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
           for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
       }
     }
-    if (++s == KS) {
-      s = 0;
-      abuf ^= 1;
-      if (++chunk == nchunk) { chunk = 0; ++r; }
+    st = (st + 1 == SB) ? 0 : st + 1;
+  };
+  auto strip = [&](auto first_tag) {
+    step(std::integral_constant<int, 0>{}, first_tag);
+    step(std::integral_constant<int, 1>{}, first_tag);
+    step(std::integral_constant<int, 2>{}, first_tag);
+    if constexpr (KS == 7) {
+      step(std::integral_constant<int, 3>{}, first_tag);
+      step(std::integral_constant<int, 4>{}, first_tag);
+      step(std::integral_constant<int, 5>{}, first_tag);
+      step(std::integral_constant<int, 6>{}, first_tag);
     }
-  }
+    abuf ^= 1;
+  };
+
+  strip(std::true_type{});
+  for (int sc = 1; sc < nstrips; ++sc) strip(std::false_type{});
+
   // drain the dummy DMAs before LDS is reused / the workgroup exits
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -222,35 +297,40 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
-  using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB>;
-  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB>;
+  using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
+  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   static std::atomic<unsigned> attr_mask{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!(attr_mask.load(std::memory_order_relaxed) & (1u << (dev & 31)))) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TR::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_mask.fetch_or(1u << (dev & 31), std::memory_order_relaxed);
   }
-  dim3 grid(P.tiles_per_img * N, P.CoutP / BN, nprob);
-  hipLaunchKernelGGL(kern, grid, dim3(256), TR::LDS_BYTES, stream, P);
+  dim3 grid(P.tiles_per_img * N * (P.CoutP / BN) * nprob);
+  static const char* ldsmax = getenv("RTP_RING_LDS_MAX");
+  const int lds = (ldsmax && ldsmax[0] == '1') ? 160 * 1024 : TR::LDS_BYTES;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, P);
   return hipGetLastError();
 }
 
 template <typename T, int KS>
 static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int nprob, int N, hipStream_t stream) {
   if (chb == 256) {
-    if (cfg == CFG_64x64) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256>(P, nprob, N, stream);
+    if (cfg == CFG_64x64) {
+      if (P.ring_sb == 4) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 4>(P, nprob, N, stream);
+      return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 6>(P, nprob, N, stream);
+    }
     return hipErrorInvalidValue;
   }
   if (chb != 128) return hipErrorInvalidValue;
   switch (cfg) {
-    case CFG_128x128: return ring_launch_one<T, 128, 128, 2, 2, 1, KS, 128>(P, nprob, N, stream);
-    case CFG_64x128: return ring_launch_one<T, 64, 128, 1, 2, 2, KS, 128>(P, nprob, N, stream);
-    case CFG_64x64: return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128>(P, nprob, N, stream);
-    case CFG_128x64: return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 128>(P, nprob, N, stream);
+    case CFG_128x128: return ring_launch_one<T, 128, 128, 2, 2, 1, KS, 128, 4>(P, nprob, N, stream);
+    case CFG_64x128: return ring_launch_one<T, 64, 128, 1, 2, 2, KS, 128, 4>(P, nprob, N, stream);
+    case CFG_64x64: return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 6>(P, nprob, N, stream);
+    case CFG_128x64: return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -392,7 +392,8 @@ int build_plan(rtp_engine* e) {
       c.impl = 0;
       if (allow_ring && !c.first && (c.k_eff == 3 || c.k_eff == 7)) {
         const int row_bytes = c.Cin_p * e->elem;
-        int chb = (best == CFG_64x64 && row_bytes % 256 == 0) ? 256 : 128;
+        static const char* f128 = getenv("RTP_RING_CHB128");
+        int chb = (best == CFG_64x64 && row_bytes % 256 == 0 && !(f128 && f128[0] == '1')) ? 256 : 128;
         if (row_bytes % chb == 0) {
           c.impl = 1;
           c.rowb = chb;
@@ -413,7 +414,7 @@ int build_plan(rtp_engine* e) {
     t.offset = off;
     off += (size_t)e->N * g.img_pix * pix_bytes + GUARD_PIX * pix_bytes;
   }
-  e->arena_bytes = round_up_sz(off, 256);
+  e->arena_bytes = round_up_sz(off, 256) + (4u << 20);  // tail pad: the ring kernel's dummy prefetches read past the last strip
   // weight arena
   size_t woff = 0;
   for (auto& c : e->convs) {
@@ -425,7 +426,7 @@ int build_plan(rtp_engine* e) {
     c.b_off = woff;
     woff += (size_t)c.CoutP * sizeof(float);
   }
-  e->weights_bytes = round_up_sz(woff, 256);
+  e->weights_bytes = round_up_sz(woff, 256) + (1u << 20);  // tail pad: dummy weight-tile prefetches of the last layer
   // dominant conv step for the roofline probe: the first paired 7x7 step whose input is not a concat
   e->dominant_step = -1;
   for (size_t si = 0; si < e->steps.size(); ++si) {
@@ -478,8 +479,10 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
         const int chunk = ci / per_chunk, kk = ci % per_chunk;
         for (int r = 0; r < c.k; ++r)
           for (int s = 0; s < c.k; ++s) {
+            // register-staged kernel: [tap][chunk]; ring kernel: step order [r][chunk][s]
             const int tap = r * c.k + s;
-            pw[((size_t)(tap * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
+            const size_t tile = c.impl == 1 ? ((size_t)(r * c.nchunk + chunk) * c.k + s) : ((size_t)tap * c.nchunk + chunk);
+            pw[(tile * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
           }
       }
   }
@@ -533,6 +536,15 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
   P.relu = A.relu ? 1 : 0;
+  P.nimg = e->N;
+  {
+    static const char* rot = getenv("RTP_CONV_ROTATE");
+    P.rotate = (rot && rot[0] == '0') ? 0 : 1;
+    static const char* xm = getenv("RTP_CONV_XCDMAP");
+    P.xcdmap = (xm && xm[0] == '0') ? 0 : 1;
+    static const char* sb = getenv("RTP_RING_SB");
+    P.ring_sb = (sb && sb[0] == '4') ? 4 : 6;
+  }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
   return RTP_OK;

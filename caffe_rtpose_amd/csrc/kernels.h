@@ -43,7 +43,11 @@ struct ConvParams {
   int nchunk;      // Cin_p*sizeof(T)/ROWB
   int CoutP;       // Cout rounded up to a multiple of BN
   int tiles_per_img;
+  int nimg;    // images (scales) in the batch
   int relu;
+  int rotate;  // ring kernel: rotate the filter-row order per tile (speed only)
+  int xcdmap;  // 1: contiguous logical range per XCD (decode_block), 0: dispatch order
+  int ring_sb; // ring depth request (4 or 6) where both are instantiated
 };
 
 // which tile configuration a conv launch uses

@@ -1,0 +1,14 @@
+#!/usr/bin/env python
+"""Run only the dominant conv launch many times (for rocprofv3 counter passes / A-B env toggles)."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import caffe_rtpose_amd as r  # noqa: E402
+prec = r.PREC_FP32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else r.PREC_FP16
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+e = r.Engine(r.Config(precision=prec, frames_in_flight=1))
+ms, fl = e.bench_dominant_conv(iters)
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("RTP_"))
+print(f"[{tag}] dominant conv {ms * 1e3:.1f} us = {fl / ms / 1e9:.1f} TFLOP/s")
+e.close()
