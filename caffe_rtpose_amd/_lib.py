@@ -70,8 +70,10 @@ SIGNATURES = {
     "rtp_last_error": (C.c_char_p, [vp]),
     "rtp_version": (C.c_char_p, []),
     "rtp_last_stage_ms": (C.c_int, [vp, fp]),
+    "rtp_debug_connect_stats": (C.c_int, [vp, ip, ip]),
     "rtp_synth_weights": (C.c_int, [C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_int, fp, fp]),
     "rtp_write_synthetic_caffemodel": (C.c_int, [C.c_int, C.c_uint64, C.c_char_p]),
+    "rtp_write_builtin_prototxt": (C.c_int, [C.c_int, C.c_char_p]),
     "rtp_caffemodel_layer": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_long), C.POINTER(C.c_long), fp]),
     "rtp_plan_summary": (C.c_long, [C.POINTER(rtp_config), C.c_char_p, C.c_size_t]),
     "rtp_bench_dominant_conv": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_double)]),

@@ -438,7 +438,7 @@ int build_plan(rtp_engine* e) {
   e->max_rows = e->num_limbs * e->max_peaks;
   {
     const size_t lds2 = (size_t)e->max_rows * (sizeof(double) + sizeof(int) + sizeof(int) * e->num_parts);
-    const size_t lds1 = (size_t)e->max_peaks * e->max_peaks * 8;
+    const size_t lds1 = 2 * (size_t)e->max_peaks * e->max_peaks * 8;
     if (lds2 > 150 * 1024 || lds1 > 150 * 1024) return fail(e, RTP_EINVAL, "max_peaks %d needs more LDS than a CU has", e->max_peaks);
   }
   return RTP_OK;
@@ -1122,6 +1122,17 @@ int rtp_prototxt_summary(const char* path, int* num_layers, int* num_conv, int* 
   return RTP_OK;
 }
 
+// Diagnostics of the last synchronous connect on context 0: survivors of the PAF test and accepted
+// connections per limb (what `temp.size()` / `connection_k.size()` were, rtpose.cpp:950,980).
+int rtp_debug_connect_stats(rtp_engine* e, int* cand_count, int* conn_count) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  Ctx& cx = e->ctx[0];
+  if (cand_count) HIPCHK(e, hipMemcpy(cand_count, cx.cand_count, e->num_limbs * sizeof(int), hipMemcpyDeviceToHost));
+  if (conn_count) HIPCHK(e, hipMemcpy(conn_count, cx.conn_count, e->num_limbs * sizeof(int), hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
 // ---- host-only weight utilities ------------------------------------------------------------------
 int rtp_synth_weights(uint64_t seed, const char* layer_name, int cout, int cin, int k, float* w, float* b) {
   if (!layer_name || !w || !b || cout < 1 || cin < 1 || k < 1) return RTP_EINVAL;
@@ -1156,6 +1167,14 @@ int rtp_write_synthetic_caffemodel(int model, uint64_t seed, const char* path) {
   std::string err;
   if (!write_caffemodel(path, net.name, lw, &err)) return fail(nullptr, RTP_EIO, "%s", err.c_str());
   return RTP_OK;
+}
+
+int rtp_write_builtin_prototxt(int model, const char* path) {
+  if (!path || (model != RTP_MODEL_COCO_18 && model != RTP_MODEL_MPI_15)) return RTP_EINVAL;
+  std::ofstream f(path);
+  if (!f) return fail(nullptr, RTP_EIO, "cannot create %s", path);
+  f << emit_prototxt(build_linevec(model));
+  return f ? RTP_OK : RTP_EIO;
 }
 
 int rtp_caffemodel_layer(const char* path, int index, char* name, int name_len, int* num_blobs, long* count0, long* count1,
@@ -1198,7 +1217,10 @@ long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
     if (!f) { delete e; return fail(nullptr, RTP_EIO, "cannot open prototxt %s", cfg->proto_path); }
     ss << f.rdbuf();
     if (!parse_prototxt(ss.str(), &e->net, &perr)) { delete e; return fail(nullptr, RTP_EIO, "%s", perr.c_str()); }
-  } else e->net = build_linevec(cfg->model);
+  } else {
+    if (cfg->model != RTP_MODEL_COCO_18 && cfg->model != RTP_MODEL_MPI_15) { delete e; return fail(nullptr, RTP_EINVAL, "unknown model %d", cfg->model); }
+    e->net = build_linevec(cfg->model);
+  }
   const int rc = build_plan(e);
   if (rc) { g_create_error = e->err; delete e; return rc; }
   std::ostringstream o;

@@ -210,15 +210,23 @@ __constant__ int kMpiMap[28] = {16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 
 
 #define CONNECT_ERR_RANGE (-34)
 
-// One workgroup per limb k.  Phase 1: PAF line integral of every (i,j) candidate pair in the
-// reference's loop order (i outer, j inner; rtpose.cpp:897-951 / :611-651), survivors compacted
-// in that order.  Phase 2 (lane 0): std::sort-exact ordering + greedy assignment (:953-980).
+// One workgroup per limb k.
+// Phase 1: PAF line integral of every (i,j) candidate pair in the reference's loop order (i outer,
+//   j inner; rtpose.cpp:897-951 / :611-651); the 10 sample addresses are computed first so that
+//   the 20 gathers of a pair are in flight together; survivors are compacted in loop order.
+// Phase 2: order the survivors as std::sort(.., ColumnCompare) would (rtpose.cpp:953-954).  If all
+//   scores are distinct the sorted order is unique, so a parallel rank sort gives it; if any two
+//   compare equal (or a NaN is present) lane 0 runs the libstdc++-exact replica instead.
+// Phase 3 (lane 0): greedy assignment (:956-980).
 __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  Cand* cands = (Cand*)lds_raw;  // [max_peaks*max_peaks]
+  const int cap = p.max_peaks * p.max_peaks;
+  Cand* cands = (Cand*)lds_raw;   // [cap]
+  Cand* sorted = cands + cap;     // [cap]
   __shared__ int wave_cnt[4];
   __shared__ int running;
   __shared__ int err;
+  __shared__ int tie;
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool coco = p.model == 0;
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
   int nA = (int)candA[0], nB = (int)candB[0];
   if (nA > p.max_peaks) nA = p.max_peaks;  // defined-behaviour clamp (see oracle NOTE)
   if (nB > p.max_peaks) nB = p.max_peaks;
-  if (tid == 0) { running = 0; err = 0; }
+  if (tid == 0) { running = 0; err = 0; tie = 0; }
   __syncthreads();
   if (nA == 0 || nB == 0) {
     if (tid == 0) { p.cand_count[k] = 0; p.conn_count[k] = 0; }
@@ -259,9 +267,9 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
       if (!(norm_vec < 1e-6)) {
         const float vec_x = d_x / norm_vec;
         const float vec_y = d_y / norm_vec;
-        float sum = 0;
-        int count = 0;
+        int idxs[10];
         bool bad = false;
+#pragma unroll
         for (int lm = 0; lm < num_inter; lm++) {
           int my = (int)roundf(s_y + lm * d_y / num_inter);
           int mx = (int)roundf(s_x + lm * d_x / num_inter);
@@ -269,9 +277,17 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
             if (mx >= NW) mx = NW - 1;
             if (my >= NH) my = NH - 1;
           }
-          if (mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; break; }
-          const int idx = my * NW + mx;
-          const float score = (vec_x * map_x[idx] + vec_y * map_y[idx]);
+          if (mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; mx = 0; my = 0; }
+          idxs[lm] = my * NW + mx;
+        }
+        float px[10], py[10];
+#pragma unroll
+        for (int lm = 0; lm < num_inter; lm++) { px[lm] = map_x[idxs[lm]]; py[lm] = map_y[idxs[lm]]; }
+        float sum = 0;
+        int count = 0;
+#pragma unroll
+        for (int lm = 0; lm < num_inter; lm++) {
+          const float score = (vec_x * px[lm] + vec_y * py[lm]);
           if (score > p.inter_threshold) {
             sum = sum + score;
             count++;
@@ -295,11 +311,29 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
     if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
   }
+  const int nc = running;
+  // ---- phase 2: rank sort (unique order) or exact replica (ties) ----
+  for (int i = tid; i < nc; i += 256) {
+    const float ki = cands[i].score;
+    int rank = 0, eq = 0;
+    if (!(ki == ki)) eq = 2;  // NaN
+    for (int j = 0; j < nc; ++j) {
+      const float kj = cands[j].score;
+      rank += (kj > ki) ? 1 : 0;
+      eq += (kj == ki) ? 1 : 0;
+    }
+    if (eq != 1) tie = 1;
+    else sorted[rank] = cands[i];
+  }
+  __syncthreads();
   if (tid != 0) return;
   if (err) { *p.num_people = CONNECT_ERR_RANGE; }
-  const int nc = running;
   p.cand_count[k] = nc;
-  std_sort_replica(cands, nc);
+  const Cand* order = sorted;
+  if (tie) {
+    std_sort_replica(cands, nc);
+    order = cands;
+  }
   const int num = nA < nB ? nA : nB;
   int cnt = 0;
   unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};  // up to 256 peaks per part
@@ -307,12 +341,13 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
   float* cs = p.conn_score + (long)k * p.max_peaks;
   for (int row = 0; row < nc; ++row) {
     if (cnt == num) break;
-    const int i = cands[row].ij >> 16, j = cands[row].ij & 0xffff;
+    const Cand c = order[row];
+    const int i = c.ij >> 16, j = c.ij & 0xffff;
     const unsigned long long ba = 1ull << ((i - 1) & 63), bb = 1ull << ((j - 1) & 63);
     if (!(occA[(i - 1) >> 6] & ba) && !(occB[(j - 1) >> 6] & bb)) {
       conn[cnt * 2] = limbSeq[2 * k] * peaks_offset + i * 3 + 2;
       conn[cnt * 2 + 1] = limbSeq[2 * k + 1] * peaks_offset + j * 3 + 2;
-      cs[cnt] = cands[row].score;
+      cs[cnt] = c.score;
       cnt++;
       occA[(i - 1) >> 6] |= ba;
       occB[(j - 1) >> 6] |= bb;
@@ -442,7 +477,7 @@ __global__ __launch_bounds__(64) void connect_assemble_kernel(ConnectParams p) {
 hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
-  const size_t lds1 = (size_t)p.max_peaks * p.max_peaks * sizeof(Cand);
+  const size_t lds1 = 2 * (size_t)p.max_peaks * p.max_peaks * sizeof(Cand);
   static bool attr1 = false, attr2 = false;
   const size_t lds2 = (size_t)p.max_rows * (sizeof(double) + sizeof(int) + sizeof(int) * p.num_parts);
   int dev = 0;

@@ -104,6 +104,12 @@ def write_synthetic_caffemodel(model, seed, path):
         raise RtpError(rc, lib.rtp_last_error(None).decode())
 
 
+def write_builtin_prototxt(model, path):
+    rc = lib.rtp_write_builtin_prototxt(model, str(path).encode())
+    if rc:
+        raise RtpError(rc, lib.rtp_last_error(None).decode())
+
+
 def read_caffemodel_layers(path):
     n = lib.rtp_caffemodel_layer(str(path).encode(), -1, None, 0, None, None, None, None)
     if n < 0:
@@ -235,6 +241,13 @@ class Engine:
         out = np.empty(tuple(shape), np.float32)
         self._chk(lib.rtp_get_blob(self.h, name.encode(), _f(out), out.size, shape))
         return out
+
+    def connect_stats(self):
+        nl = 19 if self.num_parts == 18 else 14
+        a = (C.c_int * nl)()
+        b = (C.c_int * nl)()
+        self._chk(lib.rtp_debug_connect_stats(self.h, a, b))
+        return list(a), list(b)
 
     # ---- weights
     def conv_layers(self):

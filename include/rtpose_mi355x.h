@@ -168,12 +168,18 @@ int rtp_last_stage_ms(const rtp_engine* e, float ms[5]);
  * launch.  Used by bench.py for the roofline line. */
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch);
 
+/* Survivors of the PAF test (temp.size(), rtpose.cpp:950) and accepted connections
+ * (connection_k.size(), :980) per limb for the last synchronous frame; arrays of num_limbs ints. */
+int rtp_debug_connect_stats(rtp_engine* e, int* cand_count, int* conn_count);
+
 /* Host-only weight utilities.  rtp_synth_weights: the deterministic generator behind
  * synthetic_seed (w[cout][cin][k][k], b[cout]).  rtp_write_synthetic_caffemodel: the same weights
  * for every conv of the built-in linevec net as a binary NetParameter.  rtp_caffemodel_layer:
  * read a .caffemodel (new `layer` or V1 `layers`) — index < 0 returns the layer count. */
 int rtp_synth_weights(uint64_t seed, const char* layer_name, int cout, int cin, int k, float* w, float* b);
 int rtp_write_synthetic_caffemodel(int model, uint64_t seed, const char* path);
+/* The built-in linevec graph (what proto_path == NULL uses) as deploy-prototxt text. */
+int rtp_write_builtin_prototxt(int model, const char* path);
 int rtp_caffemodel_layer(const char* path, int index, char* name, int name_len, int* num_blobs,
                          long* count0, long* count1, float* head0);
 

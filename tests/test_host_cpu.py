@@ -1,0 +1,305 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, the host
+logic behind it (graph builder / prototxt parser / plan / caffemodel IO / JSON / preprocessing /
+model tables / std::sort replica) agrees with the oracle and with fixtures derived from the
+reference.  No compute kernels are called here."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rtpose_mi355x.h")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "linevec_layers.json")
+
+
+def test_abi_library_exports_every_declared_symbol():
+    import caffe_rtpose_amd as r
+    from caffe_rtpose_amd import _lib
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(rtp_[a-z0-9_]+)\s*\(", text))
+    declared -= {"rtp_config", "rtp_engine"}
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(r.lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in r.lib.rtp_version()
+
+
+def test_no_cpu_fallback_when_no_device():
+    import torch
+    import caffe_rtpose_amd as r
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(r.RtpError) as ei:
+        r.Engine()
+    assert ei.value.code == -19  # RTP_ENODEV
+    assert b"no CPU fallback" in r.lib.rtp_last_error(None)
+
+
+def test_config_defaults_are_the_reference_flag_defaults():
+    # rtpose.cpp:50-72
+    import caffe_rtpose_amd as r
+    c = r.Config().c
+    assert (c.net_w, c.net_h, c.disp_w, c.disp_h, c.num_scales) == (656, 368, 1280, 720, 1)
+    assert c.start_scale == 1.0 and abs(c.scale_gap - 0.3) < 1e-7
+
+
+def test_model_tables_and_thresholds_match_oracle():
+    import caffe_rtpose_amd as r
+    for m in (0, 1):
+        assert r.model_tables(m) == orc.model_tables(m)
+        assert r.default_thresholds(m) == orc.default_thresholds(m)
+    with pytest.raises(r.RtpError):
+        r.model_tables(7)
+
+
+def _plan_lines(**kw):
+    import caffe_rtpose_amd as r
+    return r.plan_summary(r.Config(**kw)).strip().split("\n")
+
+
+def test_plan_coco_flops_and_pairing():
+    lines = _plan_lines()
+    assert lines[0] == "model 0 parts 18 max_peaks 64 heat_channels 57"
+    assert float(lines[-1].split()[1]) == pytest.approx(484.634, abs=1e-3)
+    convs = [l for l in lines if l.startswith("step conv")]
+    assert len(convs) == 12 + 5 + 35  # 12 VGG/CPM singles + 5 stage-1 pairs + 5x7 refinement pairs
+    assert sum(" + " in l for l in convs) == 40
+    assert any("conv4_4_CPM" in l and "dsts 6" in l for l in convs)  # own tensor + 5 concat slices
+    assert [l for l in convs if "Mconv7_stage6" in l][0].endswith("lowres 1")
+    assert sum(l.startswith("step pool") for l in lines) == 3
+    # 3 scales: same graph, 3x the work
+    l3 = _plan_lines(num_scales=3, scale_gap=0.15)
+    assert float(l3[-1].split()[1]) == pytest.approx(3 * 484.634, abs=3e-3)
+
+
+def test_plan_mpi_and_errors():
+    import caffe_rtpose_amd as r
+    lines = _plan_lines(model=1, net_w=496, net_h=368)
+    assert lines[0] == "model 1 parts 15 max_peaks 20 heat_channels 44"
+    assert float(lines[-1].split()[1]) == pytest.approx(361.695, abs=1e-3)
+    with pytest.raises(r.RtpError):
+        _plan_lines(net_w=650)  # not a multiple of 16
+    with pytest.raises(r.RtpError):
+        _plan_lines(model=5)
+
+
+def _golden_table(model):
+    g = json.load(open(GOLDEN))["coco" if model == 0 else "mpi"]
+    return g
+
+
+def _parse_prototxt_py(path):
+    t = re.sub(r"#.*", "", open(path).read())
+    out = []
+    for L in re.split(r"\nlayer \{", "\n" + t)[1:]:
+        d = {"name": re.search(r'name: "(.*?)"', L).group(1), "type": re.search(r'type: "(.*?)"', L).group(1),
+             "bottoms": re.findall(r'bottom: "(.*?)"', L), "tops": re.findall(r'top: "(.*?)"', L)}
+        for key, rx in (("num_output", r"num_output: (\d+)"), ("kernel", r"kernel_size: (\d+)"), ("pad", r"\bpad: (\d+)"),
+                        ("max_peaks", r"max_peaks: (\d+)"), ("num_parts", r"num_parts: (\d+)")):
+            m = re.search(rx, L)
+            if m:
+                d[key] = int(m.group(1))
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_builtin_graph_equals_reference_prototxt_fixture(model, tmp_path):
+    """The built-in generator vs the layer table extracted from the reference's
+    model/*/pose_deploy_linevec.prototxt (tests/golden/linevec_layers.json, made by
+    tools/make_golden_from_reference.py): same layers, order, wiring and parameters."""
+    import caffe_rtpose_amd as r
+    p = tmp_path / "builtin.prototxt"
+    r.write_builtin_prototxt(model, p)
+    mine = _parse_prototxt_py(p)
+    gold = _golden_table(model)["layers"]
+    assert len(mine) == len(gold) == 183
+    for a, b in zip(mine, gold):
+        if b["type"] == "ReLU":  # ReLU layer names carry no weights; wiring must match
+            assert a["type"] == "ReLU" and a["bottoms"] == b["bottoms"] and a["tops"] == b["tops"]
+            continue
+        for k in ("name", "type", "bottoms", "tops"):
+            assert a[k] == b[k], (a, b)
+        for k in ("num_output", "kernel", "pad", "max_peaks", "num_parts"):
+            assert a.get(k) == b.get(k), (k, a, b)
+    s = r.prototxt_summary(p)
+    assert s["num_layers"] == 183 and s["num_conv"] == 92
+    assert s["heat_channels"] == (57 if model == 0 else 44)
+
+
+@pytest.mark.parametrize("rel,model", [("model/coco/pose_deploy_linevec.prototxt", 0), ("model/mpi/pose_deploy_linevec.prototxt", 1)])
+def test_reference_prototxt_parses_to_the_same_plan(rel, model):
+    """--caffeproto on the reference's own file gives the same execution plan as the built-in graph.
+    Needs /root/reference (build container only)."""
+    import caffe_rtpose_amd as r
+    path = os.path.join("/root/reference", rel)
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this machine")
+    w, h = (656, 368) if model == 0 else (496, 368)
+    a = r.plan_summary(r.Config(model=model, net_w=w, net_h=h))
+    b = r.plan_summary(r.Config(proto_path=path, net_w=w, net_h=h))
+    assert a == b
+    s = r.prototxt_summary(path)
+    assert s["num_conv"] == 92 and s["num_parts"] == (18 if model == 0 else 15)
+    assert s["nms_threshold"] == pytest.approx(0.05 if model == 0 else 0.6)  # runtime overrides MPI to 0.2, rtpose.cpp:214
+
+
+def _varint(buf, p):
+    v = s = 0
+    while True:
+        b = buf[p]
+        p += 1
+        v |= (b & 0x7F) << s
+        if not b & 0x80:
+            return v, p
+        s += 7
+
+
+def test_caffemodel_writer_is_valid_protobuf_and_reader_roundtrips(tmp_path):
+    """Decode the written NetParameter with an independent wire-format walker (caffe.proto:64-95,
+    310-330, 10-22) and compare with the generator; then read it back through the C++ reader."""
+    import caffe_rtpose_amd as r
+    path = tmp_path / "w.caffemodel"
+    r.write_synthetic_caffemodel(1, 42, path)
+    buf = open(path, "rb").read()
+    p = 0
+    layers = []
+    while p < len(buf):
+        key, p = _varint(buf, p)
+        fn, wt = key >> 3, key & 7
+        assert wt == 2
+        n, p = _varint(buf, p)
+        if fn == 100:
+            layers.append(buf[p:p + n])
+        p += n
+    assert len(layers) == 92
+    # first layer: name, type, 2 blobs
+    L = layers[0]
+    q = 0
+    name = typ = None
+    blobs = []
+    while q < len(L):
+        key, q = _varint(L, q)
+        n, q = _varint(L, q)
+        if key >> 3 == 1:
+            name = L[q:q + n].decode()
+        elif key >> 3 == 2:
+            typ = L[q:q + n].decode()
+        elif key >> 3 == 7:
+            blobs.append(L[q:q + n])
+        q += n
+    assert (name, typ, len(blobs)) == ("conv1_1", "Convolution", 2)
+    b0 = blobs[0]
+    q = 0
+    shape = data = None
+    while q < len(b0):
+        key, q = _varint(b0, q)
+        n, q = _varint(b0, q)
+        if key >> 3 == 7:
+            sh = b0[q:q + n]
+            k2, s2 = _varint(sh, 0)
+            n2, s2 = _varint(sh, s2)
+            dims = []
+            e = s2 + n2
+            while s2 < e:
+                v, s2 = _varint(sh, s2)
+                dims.append(v)
+            shape = dims
+        elif key >> 3 == 5:
+            data = np.frombuffer(b0[q:q + n], "<f4")
+        q += n
+    assert shape == [64, 3, 3, 3]
+    w, b = r.synth_weights(42, "conv1_1", 64, 3, 3)
+    assert np.array_equal(data, w.ravel())
+    got = r.read_caffemodel_layers(path)
+    net = orc.Net(1)
+    assert [g["name"] for g in got] == [c[0] for c in net.convs]
+    for g, (nm, cin, cout, k) in zip(got, net.convs):
+        assert g["num_blobs"] == 2 and g["count0"] == cout * cin * k * k and g["count1"] == cout
+        assert np.array_equal(g["head0"], r.synth_weights(42, nm, cout, cin, k)[0].ravel()[:8])
+
+
+def test_caffemodel_reader_accepts_v1_layers_and_legacy_dims(tmp_path):
+    """V1LayerParameter (NetParameter.layers = 2: name = 4, blobs = 6) with legacy num/channels/height/
+    width blob dims (caffe.proto:17-21) and UNPACKED repeated floats."""
+    import caffe_rtpose_amd as r
+
+    def vi(v):
+        out = b""
+        while v >= 0x80:
+            out += bytes([(v & 0x7F) | 0x80])
+            v >>= 7
+        return out + bytes([v])
+
+    def field(fn, payload):
+        return vi((fn << 3) | 2) + vi(len(payload)) + payload
+
+    data = np.arange(8, dtype="<f4") * 0.5
+    blob = b"".join(vi((i << 3) | 0) + vi(d) for i, d in zip((1, 2, 3, 4), (2, 1, 2, 2)))
+    blob += b"".join(vi((5 << 3) | 5) + struct.pack("<f", float(x)) for x in data)
+    layer = field(4, b"old_conv") + field(6, blob)
+    path = tmp_path / "v1.caffemodel"
+    open(path, "wb").write(field(1, b"net") + field(2, layer))
+    got = r.read_caffemodel_layers(path)
+    assert len(got) == 1 and got[0]["name"] == "old_conv" and got[0]["count0"] == 8
+    assert np.array_equal(got[0]["head0"], data)
+
+
+def test_synthetic_weights_statistics_and_determinism():
+    import caffe_rtpose_amd as r
+    w1, b1 = r.synth_weights(1, "Mconv3_stage4_L1", 128, 128, 7)
+    w2, b2 = r.synth_weights(1, "Mconv3_stage4_L1", 128, 128, 7)
+    assert np.array_equal(w1, w2) and np.array_equal(b1, b2)
+    w3, _ = r.synth_weights(2, "Mconv3_stage4_L1", 128, 128, 7)
+    assert not np.array_equal(w1, w3)
+    assert abs(float(w1.std()) - np.sqrt(2.0 / (128 * 49))) < 2e-4 and abs(float(w1.mean())) < 1e-4
+    assert -0.1 <= b1.min() and b1.max() < 0.1
+
+
+def test_json_bytes_match_oracle_and_reference_shape():
+    """rtpose.cpp:1394-1415: `std::ofstream <<` at default precision == printf("%g")."""
+    import caffe_rtpose_amd as r
+    rs = np.random.RandomState(0)
+    for n, parts, scale in [(0, 18, 1.5), (1, 18, 1.5), (3, 15, 0.6666667), (96, 18, 2.0)]:
+        j = (rs.rand(max(n, 1), parts, 3) * np.array([1280, 720, 1])).astype(np.float32)
+        j[0, 0] = (0, 0, 0)                       # a missing part
+        j[0, 1] = (1234567.0, 1e-7, 0.000123456)  # exponent / precision edge cases of %g
+        a = r.format_json(j, n, parts, scale)
+        b = orc.write_json(j, n, parts, scale)
+        assert a == b
+        assert a.startswith(b'{\n"version":0.1,\n"bodies":[\n') and a.endswith(b"]\n}\n")
+        assert a.count(b'"joints":[') == n
+
+
+def test_process_and_pad_image_matches_oracle():
+    import caffe_rtpose_amd as r
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    for tw, th, norm in [(64, 48, 1), (53, 37, 0), (100, 90, 1)]:
+        a = r.process_and_pad_image(img, tw, th, norm)
+        b = orc.process_and_pad_image(img, tw, th, norm)
+        assert np.array_equal(a, b)
+    padw, padh = (64 - 53) // 2, (48 - 37) // 2
+    a = r.process_and_pad_image(img, 64, 48, 1)
+    assert a[2, padh, padw] == np.float32(img[0, 0, 2]) / np.float32(256.0) - np.float32(0.5)
+    assert a[:, 0, :].max() == 0 and a[:, :, 0].max() == 0  # zero padding
+    with pytest.raises(r.RtpError):
+        r.process_and_pad_image(img, 40, 48, 1)  # "Image too big for target size."
+
+
+def test_stdsort_replica_matches_libstdcxx(tmp_path):
+    """csrc/stdsort_replica.h (what the connect kernel runs on ties) vs the real std::sort on the
+    container type and comparator of rtpose.cpp:144-152,953-954, tie-heavy inputs."""
+    exe = tmp_path / "stdsort_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tests", "helpers", "stdsort_check.cpp")])
+    out = subprocess.check_output([str(exe), "1500"]).decode()
+    assert out.startswith("OK"), out

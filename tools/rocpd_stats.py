@@ -6,10 +6,15 @@ import sys
 
 
 def short(name):
-    m = re.match(r"void rtp::conv_igemm_kernel<(.*?)>\(", name)
+    m = re.match(r"_ZN3rtp(\d+)(conv_\w+_kernel)I(DF16_|f)((?:Li\d+E)+)EEvNS_10ConvParamsE", name)
     if m:
-        a = [x.strip() for x in m.group(1).split(",")]
-        return f"conv_igemm<{a[0]},BM{a[1]},BN{a[2]},W{a[3]}x{a[4]},KS{a[5]},k{a[6]},rowb{a[7]}>"
+        a = re.findall(r"Li(\d+)E", m.group(4))
+        t = "f16" if m.group(3) == "DF16_" else "f32"
+        tail = f",SB{a[7]}" if len(a) > 7 else ""
+        return f"{m.group(2)[:-7]}<{t},{a[0]}x{a[1]},w{a[2]}x{a[3]},ksplit{a[4]},k{a[5]},chb{a[6]}{tail}>"
+    m = re.match(r"_ZN3rtp\d+(\w+?)I(DF16_|f)", name)
+    if m:
+        return f"{m.group(1)}<{'f16' if m.group(2) == 'DF16_' else 'f32'}>"
     return re.sub(r"\(.*", "", name)[:90]
 
 
