@@ -88,22 +88,8 @@ def main():
             col += 1
         return people
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, 1 << 20)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from caffe_rtpose_amd.dispatch import timed_region, aggregate_fps
+    dt = timed_region(run, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     stage = eng.last_stage_ms()
 
     if rank == 0:
@@ -114,7 +100,7 @@ def main():
         achieved = flops / (ms * 1e-3)
         roof = {"bound": "mfma", "kernel": "conv_igemm 7x7 128->128 (L1+L2 pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "ms_per_launch": ms, "flops_per_launch": flops}
-        fps = world * args.steps / dt
+        fps = aggregate_fps(args.steps, world, dt)
         whole = {"achieved": fps / world * 484.634e9 * args.num_scales / 1e12, "unit": "TFLOP/s",
                  "frac": fps / world * 484.634e9 * args.num_scales / peak}
         out = {

@@ -66,6 +66,12 @@ SIGNATURES = {
     "rtp_default_thresholds": (C.c_int, [C.c_int, fp, fp, ip, ip, fp]),
     "rtp_process_and_pad_image": (C.c_int, [fp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rtp_format_json": (C.c_long, [C.c_char_p, C.c_size_t, fp, C.c_int, C.c_int, C.c_float]),
+    "rtp_display_fit_scale": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rtp_resize_area": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
+    "rtp_warp_display": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "rtp_preprocess_frame": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, fp, C.POINTER(C.c_ubyte), fp]),
+    "rtp_load_image": (C.c_int, [C.c_char_p, C.POINTER(C.c_ubyte), C.c_size_t, ip, ip]),
+    "rtp_synth_frame": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.c_uint64]),
     "rtp_prototxt_summary": (C.c_int, [C.c_char_p, ip, ip, ip, ip, fp, ip]),
     "rtp_last_error": (C.c_char_p, [vp]),
     "rtp_version": (C.c_char_p, []),

@@ -1,0 +1,286 @@
+// preprocess.cpp — host side of row a1: what getFrameFromDir/getFrameFromCam do to a
+// decoded frame before it reaches the net (rtpose.cpp:322-368, 474-518):
+//   display-fit scale -> warpAffine(INTER_CUBIC, BORDER_CONSTANT 0) to the display resolution ->
+//   per scale: cv::resize(INTER_AREA) to 16*ceil(net*s/16) -> process_and_pad_image(normalize=1).
+// OpenCV is a third-party dependency of the reference that is absent here (and whose version the
+// reference does not pin: Makefile:197-202): the two OpenCV primitives below restate OpenCV's
+// published algorithms (imgproc/imgwarp.cpp warpAffine + remap 8u cubic: 1/32-pixel fixed-point
+// coordinates, 15-bit fixed-point weights with A = -0.75; imgproc/resize.cpp computeResizeAreaTab +
+// resizeArea_: fractional-area weights, float accumulation, round-to-nearest-even).
+// PARITY UNPINNED: no test in the reference covers them; the engine's parity boundary is the float
+// NCHW tensor AFTER this stage.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/rtpose_mi355x.h"
+
+namespace {
+
+inline int cv_round(double v) { return (int)std::nearbyint(v); }  // cvRound: round half to even
+inline unsigned char sat_u8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// ---- cv::resize(..., INTER_AREA), 8UC3, shrinking in both directions -------------------------
+struct AreaTab { int di, si; float alpha; };
+void area_tab(int ssize, int dsize, double scale, std::vector<AreaTab>& tab) {
+  tab.clear();
+  for (int dx = 0; dx < dsize; dx++) {
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    const double cell = std::min(scale, ssize - fsx1);
+    int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    if (sx1 - fsx1 > 1e-3) tab.push_back({dx, sx1 - 1, (float)((sx1 - fsx1) / cell)});
+    for (int sx = sx1; sx < sx2; sx++) tab.push_back({dx, sx, (float)(1.0 / cell)});
+    if (fsx2 - sx2 > 1e-3) tab.push_back({dx, sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)});
+  }
+}
+
+void resize_linear_u8(const unsigned char* src, int sw, int sh, unsigned char* dst, int dw, int dh) {
+  // enlarging fallback (only reached when the display resolution is smaller than the net input)
+  for (int y = 0; y < dh; ++y) {
+    const float fy = (float)((y + 0.5) * sh / dh - 0.5);
+    int y0 = (int)std::floor(fy);
+    const float wy = fy - y0;
+    const int y1 = std::min(std::max(y0 + 1, 0), sh - 1);
+    y0 = std::min(std::max(y0, 0), sh - 1);
+    for (int x = 0; x < dw; ++x) {
+      const float fx = (float)((x + 0.5) * sw / dw - 0.5);
+      int x0 = (int)std::floor(fx);
+      const float wx = fx - x0;
+      const int x1 = std::min(std::max(x0 + 1, 0), sw - 1);
+      x0 = std::min(std::max(x0, 0), sw - 1);
+      for (int c = 0; c < 3; ++c) {
+        const float a = src[(y0 * sw + x0) * 3 + c] * (1 - wx) + src[(y0 * sw + x1) * 3 + c] * wx;
+        const float b = src[(y1 * sw + x0) * 3 + c] * (1 - wx) + src[(y1 * sw + x1) * 3 + c] * wx;
+        dst[(y * dw + x) * 3 + c] = sat_u8(cv_round(a * (1 - wy) + b * wy));
+      }
+    }
+  }
+}
+
+void resize_area_u8(const unsigned char* src, int sw, int sh, unsigned char* dst, int dw, int dh) {
+  if (dw == sw && dh == sh) { memcpy(dst, src, (size_t)sw * sh * 3); return; }
+  if (dw > sw || dh > sh) { resize_linear_u8(src, sw, sh, dst, dw, dh); return; }
+  const double sx = (double)sw / dw, sy = (double)sh / dh;
+  std::vector<AreaTab> xt, yt;
+  area_tab(sw, dw, sx, xt);
+  area_tab(sh, dh, sy, yt);
+  std::vector<float> buf((size_t)dw * 3), sum((size_t)dw * 3);
+  size_t yi = 0;
+  for (int dy = 0; dy < dh; ++dy) {
+    std::fill(sum.begin(), sum.end(), 0.f);
+    for (; yi < yt.size() && yt[yi].di == dy; ++yi) {
+      const unsigned char* srow = src + (size_t)yt[yi].si * sw * 3;
+      const float beta = yt[yi].alpha;
+      std::fill(buf.begin(), buf.end(), 0.f);
+      for (const AreaTab& t : xt)
+        for (int c = 0; c < 3; ++c) buf[t.di * 3 + c] += srow[t.si * 3 + c] * t.alpha;
+      for (int i = 0; i < dw * 3; ++i) sum[i] += beta * buf[i];
+    }
+    for (int i = 0; i < dw * 3; ++i) dst[(size_t)dy * dw * 3 + i] = sat_u8(cv_round(sum[i]));
+  }
+}
+
+// ---- cv::warpAffine(src, dst, M = diag(scale), dsize, INTER_CUBIC, BORDER_CONSTANT, 0) ---------
+void cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale, unsigned char* dst, int dw, int dh) {
+  const int INTER_BITS = 5, INTER_TAB = 1 << INTER_BITS, AB_BITS = 10, AB_SCALE = 1 << AB_BITS, COEF_BITS = 15;
+  // 1-D cubic tables in 15-bit fixed point (initInterTab2D: weights sum to 1 << 15, the remainder goes to the largest)
+  short tab[32][4];
+  for (int i = 0; i < INTER_TAB; ++i) {
+    float c[4];
+    cubic_coeffs((float)i / INTER_TAB, c);
+    int isum = 0, kmax = 0;
+    for (int k = 0; k < 4; ++k) { tab[i][k] = (short)cv_round(c[k] * (1 << COEF_BITS)); isum += tab[i][k]; if (c[k] > c[kmax]) kmax = k; }
+    tab[i][kmax] = (short)(tab[i][kmax] + ((1 << COEF_BITS) - isum));
+  }
+  const double inv = 1.0 / scale;  // warpAffine inverts M unless WARP_INVERSE_MAP
+  const int round_delta = AB_SCALE / INTER_TAB / 2;
+  for (int y = 0; y < dh; ++y) {
+    const int Y0 = (int)std::lrint((inv * y) * AB_SCALE) + round_delta;
+    const int Y = Y0 >> (AB_BITS - INTER_BITS);
+    const int sy = (Y >> INTER_BITS) - 1, fy = Y & (INTER_TAB - 1);
+    for (int x = 0; x < dw; ++x) {
+      const int X0 = (int)std::lrint((inv * x) * AB_SCALE) + round_delta;
+      const int X = X0 >> (AB_BITS - INTER_BITS);
+      const int sx = (X >> INTER_BITS) - 1, fx = X & (INTER_TAB - 1);
+      for (int c = 0; c < 3; ++c) {
+        long acc = 0;
+        for (int r = 0; r < 4; ++r) {
+          const int yy = sy + r;
+          if (yy < 0 || yy >= sh) continue;  // BORDER_CONSTANT 0
+          int row = 0;
+          for (int q = 0; q < 4; ++q) {
+            const int xx = sx + q;
+            if (xx < 0 || xx >= sw) continue;
+            row += src[((size_t)yy * sw + xx) * 3 + c] * tab[fx][q];
+          }
+          acc += (long)row * tab[fy][r];
+        }
+        dst[((size_t)y * dw + x) * 3 + c] = sat_u8((int)((acc + (1L << (2 * COEF_BITS - 1))) >> (2 * COEF_BITS)));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// rtpose.cpp:324-329: scale-to-fit, top-left anchored
+double rtp_display_fit_scale(int ow, int oh, int disp_w, int disp_h) {
+  if (ow / (double)oh > disp_w / (double)disp_h) return disp_w / (double)ow;
+  return disp_h / (double)oh;
+}
+
+int rtp_resize_area(const unsigned char* bgr, int sw, int sh, unsigned char* out, int dw, int dh) {
+  if (!bgr || !out || sw < 1 || sh < 1 || dw < 1 || dh < 1) return RTP_EINVAL;
+  resize_area_u8(bgr, sw, sh, out, dw, dh);
+  return RTP_OK;
+}
+
+int rtp_warp_display(const unsigned char* bgr, int sw, int sh, unsigned char* out, int disp_w, int disp_h, double* scale_out) {
+  if (!bgr || !out || sw < 1 || sh < 1 || disp_w < 1 || disp_h < 1) return RTP_EINVAL;
+  const double s = rtp_display_fit_scale(sw, sh, disp_w, disp_h);
+  warp_scale_cubic_u8(bgr, sw, sh, s, out, disp_w, disp_h);
+  if (scale_out) *scale_out = s;
+  return RTP_OK;
+}
+
+// The producer's per-frame work (rtpose.cpp:322-368): returns the net input (num_scales x 3 x net_h x
+// net_w) and Frame::scale.  display_bgr (disp_h x disp_w x 3) may be NULL.
+int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h, int num_scales,
+                         double start_scale, double scale_gap, float* net_input, unsigned char* display_bgr, float* frame_scale) {
+  if (!bgr || !net_input || w < 1 || h < 1 || num_scales < 1) return RTP_EINVAL;
+  std::vector<unsigned char> disp((size_t)disp_w * disp_h * 3);
+  double s = 0;
+  int rc = rtp_warp_display(bgr, w, h, disp.data(), disp_w, disp_h, &s);
+  if (rc) return rc;
+  if (frame_scale) *frame_scale = (float)s;
+  if (display_bgr) memcpy(display_bgr, disp.data(), disp.size());
+  const size_t offset = (size_t)3 * net_h * net_w;
+  std::vector<unsigned char> tmp;
+  for (int i = 0; i < num_scales; ++i) {
+    const float scale = (float)(start_scale - i * scale_gap);
+    const int tw = (int)(16 * std::ceil(net_w * scale / 16));
+    const int th = (int)(16 * std::ceil(net_h * scale / 16));
+    if (tw > net_w || th > net_h || tw < 16 || th < 16) return RTP_EINVAL;  // CHECK_LE(target_width, NET_RESOLUTION_WIDTH)
+    tmp.resize((size_t)tw * th * 3);
+    resize_area_u8(disp.data(), disp_w, disp_h, tmp.data(), tw, th);
+    rc = rtp_process_and_pad_image(net_input + i * offset, tmp.data(), tw, th, net_w, net_h, 1);
+    if (rc) return rc;
+  }
+  return RTP_OK;
+}
+
+// ---- image files we can decode without OpenCV: binary PPM (P6) and 24-bit uncompressed BMP ------
+int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h) {
+  if (!path || !w || !h) return RTP_EINVAL;
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return RTP_EIO;
+  unsigned char magic[2] = {0, 0};
+  f.read((char*)magic, 2);
+  if (magic[0] == 'P' && magic[1] == '6') {
+    auto next_int = [&]() {
+      int c = f.get();
+      for (;;) {
+        while (c == ' ' || c == '\n' || c == '\r' || c == '\t') c = f.get();
+        if (c == '#') { while (c != '\n' && c != EOF) c = f.get(); continue; }
+        break;
+      }
+      int v = 0;
+      while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = f.get(); }
+      return v;
+    };
+    const int W = next_int(), H = next_int(), maxv = next_int();
+    if (W < 1 || H < 1 || maxv != 255) return RTP_EIO;
+    *w = W; *h = H;
+    if (!out_bgr) return RTP_OK;
+    if (capacity < (size_t)W * H * 3) return RTP_EINVAL;
+    f.read((char*)out_bgr, (std::streamsize)W * H * 3);
+    if (!f) return RTP_EIO;
+    for (size_t i = 0; i < (size_t)W * H; ++i) std::swap(out_bgr[i * 3], out_bgr[i * 3 + 2]);  // RGB -> BGR
+    return RTP_OK;
+  }
+  if (magic[0] == 'B' && magic[1] == 'M') {
+    unsigned char hdr[52];
+    f.read((char*)hdr, 52);
+    if (!f) return RTP_EIO;
+    auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
+    const uint32_t data_off = u32(8);
+    const int32_t W = (int32_t)u32(16), Hs = (int32_t)u32(20);
+    const int bpp = hdr[26] | (hdr[27] << 8);
+    const uint32_t comp = u32(28);
+    if (W < 1 || Hs == 0 || bpp != 24 || comp != 0) return RTP_EIO;
+    const int H = Hs < 0 ? -Hs : Hs;
+    *w = W; *h = H;
+    if (!out_bgr) return RTP_OK;
+    if (capacity < (size_t)W * H * 3) return RTP_EINVAL;
+    const size_t stride = ((size_t)W * 3 + 3) & ~(size_t)3;
+    std::vector<unsigned char> row(stride);
+    f.seekg(data_off);
+    for (int y = 0; y < H; ++y) {
+      f.read((char*)row.data(), (std::streamsize)stride);
+      if (!f) return RTP_EIO;
+      const int dy = Hs < 0 ? y : H - 1 - y;
+      memcpy(out_bgr + (size_t)dy * W * 3, row.data(), (size_t)W * 3);
+    }
+    return RTP_OK;
+  }
+  return RTP_EIO;  // JPEG/PNG need a codec this image does not have
+}
+
+// Procedural frame `index` of the synthetic video (BASELINE config 2: "synthetic 720p video"):
+// a textured background with moving bright stick figures; deterministic in (seed, index).
+int rtp_synth_frame(unsigned char* out_bgr, int w, int h, int index, uint64_t seed) {
+  if (!out_bgr || w < 16 || h < 16) return RTP_EINVAL;
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+  auto rnd = [&]() { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const unsigned v = (unsigned)(((x * 7 + y * 13 + index * 3) ^ (x * y >> 4)) & 63);
+      unsigned char* p = out_bgr + ((size_t)y * w + x) * 3;
+      p[0] = (unsigned char)(40 + v); p[1] = (unsigned char)(50 + v / 2); p[2] = (unsigned char)(60 + (v ^ 21) / 2);
+    }
+  const int people = 3;
+  for (int pi = 0; pi < people; ++pi) {
+    const double cx = (double)(rnd() % 1000) / 1000.0 * 0.6 + 0.2 + 0.15 * std::sin(index * 0.05 + pi);
+    const double cy = 0.15 + 0.05 * pi;
+    const double size = 0.5 + 0.1 * pi;
+    auto line = [&](double x0, double y0, double x1, double y1, int thick, unsigned char b, unsigned char g, unsigned char r) {
+      const int n = (int)(std::max(std::fabs(x1 - x0), std::fabs(y1 - y0)) * std::max(w, h)) + 1;
+      for (int i = 0; i <= n; ++i) {
+        const int px = (int)((x0 + (x1 - x0) * i / n) * w), py = (int)((y0 + (y1 - y0) * i / n) * h);
+        for (int dy = -thick; dy <= thick; ++dy)
+          for (int dx = -thick; dx <= thick; ++dx) {
+            const int xx = px + dx, yy = py + dy;
+            if (xx >= 0 && xx < w && yy >= 0 && yy < h) { unsigned char* p = out_bgr + ((size_t)yy * w + xx) * 3; p[0] = b; p[1] = g; p[2] = r; }
+          }
+      }
+    };
+    const double sw = 0.08 * size, top = cy, neck = cy + 0.08 * size, hip = cy + 0.45 * size, foot = cy + 0.9 * size;
+    line(cx, top, cx, neck, 6, 200, 180, 220);
+    line(cx - sw, neck, cx + sw, neck, 4, 90, 200, 240);
+    line(cx, neck, cx, hip, 5, 90, 200, 240);
+    line(cx - sw, neck, cx - 1.5 * sw, hip, 3, 240, 160, 90);
+    line(cx + sw, neck, cx + 1.5 * sw, hip, 3, 240, 160, 90);
+    line(cx, hip, cx - sw, foot, 4, 120, 240, 120);
+    line(cx, hip, cx + sw, foot, 4, 120, 240, 120);
+  }
+  return RTP_OK;
+}
+
+}  // extern "C"

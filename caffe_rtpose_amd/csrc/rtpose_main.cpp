@@ -1,0 +1,381 @@
+// rtpose_main.cpp — rtpose.bin: the reference's CLI surface (examples/rtpose/rtpose.cpp:50-72,
+// 1674-1780) over the MI355X engine.  Thread structure follows rtcpm() (rtpose.cpp:1459-1547):
+//   1 producer (decode/generate -> display-fit warp -> scale pyramid -> net input)   :302/393
+//   NUM_GPU workers, one engine each, all pulling from ONE shared queue              :1099-1203
+//   1 re-orderer (min-heap on frame.index, window BUFFER_SIZE = 4, skips dropped)    :1214-1273
+//   1 writer (JSON, latency log every 30 frames)                                     :1315-1454
+// There is no collective: frames are independent.  Differences from the reference,
+// all forced by the environment: no display/camera (no GUI stack), image decoding limited to
+// PPM/BMP (no codecs), `--video synthetic:WxH:frames[:seed]` generates frames procedurally, and the
+// process exits at end of input also without --write_frames (the reference loops the video forever).
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <dirent.h>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtpose_mi355x.h"
+
+extern "C" {
+double rtp_display_fit_scale(int ow, int oh, int disp_w, int disp_h);
+int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h, int num_scales,
+                         double start_scale, double scale_gap, float* net_input, unsigned char* display_bgr, float* frame_scale);
+int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h);
+int rtp_synth_frame(unsigned char* out_bgr, int w, int h, int index, uint64_t seed);
+}
+
+namespace {
+
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- flags (names and defaults: rtpose.cpp:50-72) --------------------------------------------
+struct Flags {
+  bool fullscreen = false, no_frame_drops = false, no_display = false, no_text = false, logtostderr = false;
+  int part_to_show = 0, camera = 0, start_frame = 0, start_device = 0, num_gpu = 1, num_scales = 1;
+  std::string write_frames, write_json, video, image_dir;
+  std::string caffemodel = "model/coco/pose_iter_440000.caffemodel", caffeproto = "model/coco/pose_deploy_linevec.prototxt";
+  std::string resolution = "1280x720", net_resolution = "656x368", camera_resolution = "1280x720";
+  double start_scale = 1, scale_gap = 0.3;
+  // extensions (not in the reference)
+  std::string precision = "fp16", model = "";  // --model coco|mpi: use the built-in graph + synthetic weights
+  int frames_in_flight = 2;
+  unsigned long long synthetic_seed = 1;
+};
+
+int parse_flags(int argc, char** argv, Flags& F) {
+  std::map<std::string, std::string*> sflags = {{"write_frames", &F.write_frames}, {"write_json", &F.write_json}, {"video", &F.video},
+      {"image_dir", &F.image_dir}, {"caffemodel", &F.caffemodel}, {"caffeproto", &F.caffeproto}, {"resolution", &F.resolution},
+      {"net_resolution", &F.net_resolution}, {"camera_resolution", &F.camera_resolution}, {"precision", &F.precision}, {"model", &F.model}};
+  std::map<std::string, int*> iflags = {{"part_to_show", &F.part_to_show}, {"camera", &F.camera}, {"start_frame", &F.start_frame},
+      {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}};
+  std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}};
+  std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"no_display", &F.no_display},
+      {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}};
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "--help" || a == "-help" || a == "-h") return 2;
+    if (a.size() < 2 || a[0] != '-') { fprintf(stderr, "ERROR: unexpected argument '%s'\n", a.c_str()); return 1; }
+    a = a.substr(a[1] == '-' ? 2 : 1);
+    std::string val;
+    bool has_val = false;
+    const size_t eq = a.find('=');
+    if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); has_val = true; }
+    if (bflags.count(a)) {
+      if (has_val) *bflags[a] = (val == "true" || val == "1");
+      else *bflags[a] = true;
+      continue;
+    }
+    if (a.rfind("no", 0) == 0 && bflags.count(a.substr(2)) && !has_val) { *bflags[a.substr(2)] = false; continue; }  // gflags --noflag
+    if (!sflags.count(a) && !iflags.count(a) && !dflags.count(a) && a != "synthetic_seed") {
+      fprintf(stderr, "ERROR: unknown command line flag '%s'\n", a.c_str());
+      return 1;
+    }
+    if (!has_val) {
+      if (i + 1 >= argc) { fprintf(stderr, "ERROR: flag '%s' is missing its argument\n", a.c_str()); return 1; }
+      val = argv[++i];
+    }
+    if (sflags.count(a)) *sflags[a] = val;
+    else if (iflags.count(a)) *iflags[a] = atoi(val.c_str());
+    else if (dflags.count(a)) *dflags[a] = atof(val.c_str());
+    else F.synthetic_seed = strtoull(val.c_str(), nullptr, 10);
+  }
+  return 0;
+}
+
+void usage() {
+  printf("rtpose.bin (MI355X engine) — flags as examples/rtpose/rtpose.cpp:\n"
+         "  --video PATH|synthetic:WxH:frames[:seed]   --image_dir DIR (ppm/bmp)   --camera N (unsupported)\n"
+         "  --caffeproto FILE --caffemodel FILE   | --model coco|mpi (built-in graph, synthetic weights)\n"
+         "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
+         "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
+         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K]\n");
+}
+
+// ---- queues (caffe::BlockingQueue, util/blocking_queue.cpp:26-61) -----------------------------
+template <typename T> class BlockingQueue {
+ public:
+  void push(T v) { { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(v)); } cv_.notify_one(); }
+  bool try_pop(T* v) { std::lock_guard<std::mutex> l(m_); if (q_.empty()) return false; *v = std::move(q_.front()); q_.pop_front(); return true; }
+  bool pop_wait(T* v, std::atomic<bool>& quit) {
+    std::unique_lock<std::mutex> l(m_);
+    while (q_.empty()) { if (quit.load()) return false; cv_.wait_for(l, std::chrono::milliseconds(2)); }
+    *v = std::move(q_.front()); q_.pop_front();
+    return true;
+  }
+  size_t size() { std::lock_guard<std::mutex> l(m_); return q_.size(); }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<T> q_;
+};
+
+// include/caffe/cpm/frame.h:6-34
+struct Frame {
+  std::vector<float> data;  // net input
+  double commit_time = 0, preprocessed_time = 0, gpu_fetched_time = 0, gpu_computed_time = 0, buffer_start_time = 0, buffer_end_time = 0;
+  int index = 0, numPeople = 0, video_frame_number = 0;
+  float scale = 1.f;
+  std::string stem;
+  std::vector<float> joints;
+};
+
+struct Global {
+  BlockingQueue<Frame> input_queue, output_queue, output_queue_ordered;
+  std::priority_queue<int, std::vector<int>, std::greater<int>> dropped_index;
+  std::mutex mutex;
+  std::atomic<bool> quit_threads{false};
+  std::atomic<int> produced{0}, finished{0}, dropped{0};
+  std::atomic<bool> producer_done{false};
+  int num_parts = 18;
+  std::vector<std::string> image_list;
+};
+
+Flags F;
+Global G;
+int DISP_W, DISP_H, NET_W, NET_H;
+const int BUFFER_SIZE = 4;  // rtpose.cpp:90
+
+bool mkdir_p(const std::string& d) { struct stat st; if (stat(d.c_str(), &st) == 0) return S_ISDIR(st.st_mode); return mkdir(d.c_str(), 0755) == 0; }
+
+// ---- producer -----------------------------------------------------------------------------------
+void producer() {
+  int global_counter = 1;
+  int sw = 0, sh = 0, nframes = 0;
+  unsigned long long seed = 2;
+  const bool synthetic = F.video.rfind("synthetic:", 0) == 0;
+  if (synthetic) {
+    if (sscanf(F.video.c_str(), "synthetic:%dx%d:%d:%llu", &sw, &sh, &nframes, &seed) < 3) { fprintf(stderr, "bad --video %s\n", F.video.c_str()); G.quit_threads = true; return; }
+  } else nframes = (int)G.image_list.size();
+  std::vector<unsigned char> img;
+  for (int fi = F.start_frame; fi < nframes && !G.quit_threads; ++fi) {
+    // back-pressure (rtpose.cpp:311, 424-429)
+    while (G.input_queue.size() > 10 && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    Frame fr;
+    int w = sw, h = sh;
+    if (synthetic) {
+      img.resize((size_t)w * h * 3);
+      rtp_synth_frame(img.data(), w, h, fi, seed);
+      char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm;
+    } else {
+      const std::string& path = G.image_list[fi];
+      if (rtp_load_image(path.c_str(), nullptr, 0, &w, &h) != RTP_OK) { fprintf(stderr, "cannot decode %s (only PPM/BMP without OpenCV)\n", path.c_str()); continue; }
+      img.resize((size_t)w * h * 3);
+      if (rtp_load_image(path.c_str(), img.data(), img.size(), &w, &h) != RTP_OK) continue;
+      size_t sl = path.find_last_of('/'), dot = path.find_last_of('.');
+      fr.stem = path.substr(sl == std::string::npos ? 0 : sl + 1, dot - (sl == std::string::npos ? 0 : sl + 1));
+    }
+    fr.commit_time = wall();
+    fr.data.resize((size_t)F.num_scales * 3 * NET_H * NET_W);
+    if (rtp_preprocess_frame(img.data(), w, h, DISP_W, DISP_H, NET_W, NET_H, F.num_scales, F.start_scale, F.scale_gap, fr.data.data(), nullptr, &fr.scale) != RTP_OK) {
+      fprintf(stderr, "preprocess failed for frame %d\n", fi);
+      continue;
+    }
+    fr.index = global_counter++;
+    fr.video_frame_number = fi;
+    fr.preprocessed_time = wall();
+    G.produced++;
+    G.input_queue.push(std::move(fr));
+  }
+  G.producer_done = true;
+}
+
+// ---- per-GPU worker (processFrame, rtpose.cpp:1079-1203) -----------------------------------------
+void worker(int device, int* status) {
+  rtp_config cfg;
+  rtp_config_default(&cfg);
+  cfg.device_id = device;
+  if (!F.model.empty()) cfg.model = (F.model == "mpi") ? RTP_MODEL_MPI_15 : RTP_MODEL_COCO_18;
+  else { cfg.proto_path = F.caffeproto.c_str(); cfg.weights_path = F.caffemodel.c_str(); }
+  cfg.synthetic_seed = F.synthetic_seed;
+  cfg.net_w = NET_W; cfg.net_h = NET_H; cfg.num_scales = F.num_scales;
+  cfg.start_scale = (float)F.start_scale; cfg.scale_gap = (float)F.scale_gap;
+  cfg.disp_w = DISP_W; cfg.disp_h = DISP_H;
+  cfg.precision = F.precision == "fp32" ? RTP_PREC_FP32 : RTP_PREC_FP16;
+  cfg.frames_in_flight = F.frames_in_flight;
+  rtp_engine* e = nullptr;
+  if (rtp_engine_create(&cfg, &e) != RTP_OK) {
+    fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));
+    *status = 1;
+    G.quit_threads = true;
+    return;
+  }
+  int num_parts = 18;
+  rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
+  G.num_parts = num_parts;
+  fprintf(stderr, "GPU %d is ready\n", device);
+  std::deque<Frame> inflight;
+  std::vector<float> joints((size_t)RTP_MAX_PEOPLE * num_parts * 3);
+  auto collect_one = [&]() {
+    uint64_t tag;
+    int n = 0;
+    Frame fr = std::move(inflight.front());
+    inflight.pop_front();
+    const int rc = rtp_collect(e, &tag, joints.data(), &n);
+    if (rc != RTP_OK) { fprintf(stderr, "GPU %d frame %d: %s\n", device, fr.index, rtp_last_error(e)); n = 0; }
+    fr.numPeople = n;
+    fr.joints.assign(joints.begin(), joints.begin() + (size_t)n * num_parts * 3);
+    fr.gpu_computed_time = wall();
+    fr.data.clear();
+    fr.data.shrink_to_fit();
+    G.output_queue.push(std::move(fr));
+  };
+  while (!G.quit_threads) {
+    Frame fr;
+    bool got = (int)inflight.size() < F.frames_in_flight && G.input_queue.try_pop(&fr);
+    if (got) {
+      fr.gpu_fetched_time = wall();
+      if (fr.gpu_fetched_time - fr.commit_time > 0.1 && !F.no_frame_drops) {  // rtpose.cpp:1112-1124
+        std::lock_guard<std::mutex> l(G.mutex);
+        G.dropped_index.push(fr.index);
+        G.dropped++;
+        continue;
+      }
+      if (rtp_submit(e, fr.data.data(), (uint64_t)fr.index) != RTP_OK) { fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(e)); *status = 1; break; }
+      inflight.push_back(std::move(fr));
+      if ((int)inflight.size() < F.frames_in_flight) continue;
+    }
+    if (!inflight.empty()) collect_one();
+    else if (G.producer_done && G.input_queue.size() == 0) break;
+    else std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  while (!inflight.empty()) collect_one();
+  rtp_engine_destroy(e);
+}
+
+// ---- re-orderer (buffer_and_order, rtpose.cpp:1214-1273) ---------------------------------------------
+struct FrameCompare { bool operator()(const Frame& a, const Frame& b) const { return a.index > b.index; } };
+void reorderer(std::atomic<bool>* workers_done) {
+  std::priority_queue<Frame, std::vector<Frame>, FrameCompare> buffer;
+  int frame_waited = 1;
+  auto skip_dropped = [&]() {
+    std::lock_guard<std::mutex> l(G.mutex);
+    while (!G.dropped_index.empty() && G.dropped_index.top() == frame_waited) { frame_waited++; G.dropped_index.pop(); }
+  };
+  auto emit = [&](Frame f) { f.buffer_end_time = wall(); G.output_queue_ordered.push(std::move(f)); };
+  while (true) {
+    Frame fr;
+    if (!G.output_queue.try_pop(&fr)) {
+      if (workers_done->load() && G.output_queue.size() == 0) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
+    }
+    fr.buffer_start_time = wall();
+    skip_dropped();
+    if (fr.index == frame_waited) {
+      emit(std::move(fr));
+      frame_waited++;
+      skip_dropped();
+      while (!buffer.empty() && buffer.top().index == frame_waited) { emit(buffer.top()); buffer.pop(); frame_waited++; skip_dropped(); }
+    } else buffer.push(std::move(fr));
+    if ((int)buffer.size() > BUFFER_SIZE) {  // window overflow: force-emit the smallest
+      Frame extra = buffer.top();
+      buffer.pop();
+      frame_waited = extra.index + 1;
+      emit(std::move(extra));
+      while (!buffer.empty() && buffer.top().index == frame_waited) { emit(buffer.top()); buffer.pop(); frame_waited++; }
+    }
+  }
+  while (!buffer.empty()) { emit(buffer.top()); buffer.pop(); }
+}
+
+// ---- writer (displayFrame, rtpose.cpp:1315-1454) -------------------------------------------------------
+void writer(std::atomic<bool>* reorder_done) {
+  int counter = 1;
+  double last_time = wall();
+  std::vector<char> buf(1 << 20);
+  while (true) {
+    Frame fr;
+    if (!G.output_queue_ordered.try_pop(&fr)) {
+      if (reorder_done->load() && G.output_queue_ordered.size() == 0) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
+    }
+    if (!F.write_json.empty()) {
+      char fname[1024];
+      if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.json", F.write_json.c_str(), fr.video_frame_number);  // :1388
+      else snprintf(fname, sizeof fname, "%s/%s.json", F.write_json.c_str(), fr.stem.c_str());                                   // :1390-1393
+      const long n = rtp_format_json(buf.data(), buf.size(), fr.joints.data(), fr.numPeople, G.num_parts, fr.scale);
+      if (n >= 0) { std::ofstream fs(fname, std::ios::binary); fs.write(buf.data(), n); }
+      else fprintf(stderr, "JSON buffer too small for frame %d\n", fr.index);
+    }
+    G.finished++;
+    counter++;
+    if (counter % 30 == 0) {  // rtpose.cpp:1421-1441
+      const double now = wall();
+      const double fps = 30.0 / (now - last_time);
+      last_time = now;
+      fprintf(stderr, "# %d, NP %d, Latency %.3f, Preprocess %.3f, QueueA %.3f, GPU %.3f, QueueB %.3f, Buffered %.3f, QueueD %.3f, FPS = %.1f\n",
+              fr.index, fr.numPeople, now - fr.commit_time, fr.preprocessed_time - fr.commit_time, fr.gpu_fetched_time - fr.preprocessed_time,
+              fr.gpu_computed_time - fr.gpu_fetched_time, fr.buffer_start_time - fr.gpu_computed_time, fr.buffer_end_time - fr.buffer_start_time,
+              now - fr.buffer_end_time, fps);
+    }
+  }
+}
+
+int read_image_dir() {  // readImageDirIfFlagEnabled, rtpose.cpp:1732-1755
+  if (F.image_dir.empty()) return 0;
+  DIR* d = opendir(F.image_dir.c_str());
+  if (!d) { fprintf(stderr, "Folder %s does not exist.\n", F.image_dir.c_str()); return -1; }
+  while (dirent* ent = readdir(d)) {
+    const std::string n = ent->d_name;
+    const size_t dot = n.find_last_of('.');
+    if (dot == std::string::npos) continue;
+    const std::string ext = n.substr(dot);
+    if (ext == ".jpg" || ext == ".png" || ext == ".bmp" || ext == ".ppm") G.image_list.push_back(F.image_dir + "/" + n);
+  }
+  closedir(d);
+  std::sort(G.image_list.begin(), G.image_list.end());
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const int pf = parse_flags(argc, argv, F);
+  if (pf == 2) { usage(); return 0; }
+  if (pf) return 1;
+  if (sscanf(F.resolution.c_str(), "%dx%d", &DISP_W, &DISP_H) != 2) { fprintf(stderr, "Error, resolution format (%s) invalid, should be e.g., 960x540\n", F.resolution.c_str()); return 1; }
+  if (sscanf(F.net_resolution.c_str(), "%dx%d", &NET_W, &NET_H) != 2) { fprintf(stderr, "Error, net resolution format (%s) invalid, should be e.g., 656x368 (multiples of 16)\n", F.net_resolution.c_str()); return 1; }
+  if (read_image_dir() != 0) return 1;
+  if (DISP_W == -1) {  // rtpose.cpp:1676-1693
+    int w = 0, h = 0;
+    if (!F.image_dir.empty() && !G.image_list.empty() && rtp_load_image(G.image_list[0].c_str(), nullptr, 0, &w, &h) == RTP_OK) { DISP_W = w; DISP_H = h; }
+    else if (F.video.rfind("synthetic:", 0) == 0 && sscanf(F.video.c_str(), "synthetic:%dx%d", &w, &h) == 2) { DISP_W = w; DISP_H = h; }
+    else { fprintf(stderr, "Invalid resolution without video/images: %dx%d\n", DISP_W, DISP_H); return 1; }
+  }
+  if (F.video.empty() && F.image_dir.empty()) { fprintf(stderr, "Couldn't open camera %d (no capture stack in this build): use --video or --image_dir\n", F.camera); return 1; }
+  if (!F.video.empty() && F.video.rfind("synthetic:", 0) != 0) { fprintf(stderr, "Couldn't open video file %s (no codecs in this build): use synthetic:WxH:frames or --image_dir\n", F.video.c_str()); return 1; }
+  for (const std::string* d : {&F.write_frames, &F.write_json})
+    if (!d->empty() && !mkdir_p(*d)) { fprintf(stderr, "Could not write to or create directory %s\n", d->c_str()); return 1; }
+  if (F.num_gpu < 1) { fprintf(stderr, "--num_gpu must be >= 1\n"); return 1; }
+
+  const double t0 = wall();
+  std::vector<std::thread> workers;
+  std::vector<int> status(F.num_gpu, 0);
+  for (int g = 0; g < F.num_gpu; ++g) workers.emplace_back(worker, g + F.start_device, &status[g]);
+  std::atomic<bool> workers_done{false}, reorder_done{false};
+  std::thread prod(producer), reo(reorderer, &workers_done), wr(writer, &reorder_done);
+  prod.join();
+  for (auto& t : workers) t.join();
+  workers_done = true;
+  reo.join();
+  reorder_done = true;
+  wr.join();
+  int rc = 0;
+  for (int s : status) rc |= s;
+  const double dt = wall() - t0;
+  fprintf(stderr, "rtcpm %s. Total time: %.3f seconds. frames produced %d, written %d, dropped %d (%.1f FPS incl. init)\n",
+          rc ? "FAILED" : "successfully finished", dt, G.produced.load(), G.finished.load(), G.dropped.load(), G.finished.load() / dt);
+  return rc;
+}

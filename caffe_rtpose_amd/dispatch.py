@@ -1,0 +1,46 @@
+"""Frame sharding + timing helpers for multi-GPU runs (one process per GPU, torch.distributed).
+
+The reference shards FRAMES across GPUs with full replicas and no collective on the data path
+(rtpose.cpp:1463-1472,1107).  In-process that is rtpose.bin's shared queue; across
+processes (bench.py under torch.distributed.run) every rank owns a contiguous block of the frame
+indices, and the only communication is the barrier / MAX-reduce around the timed region.
+"""
+import time
+
+
+def frame_shard(total_frames, rank, world):
+    """Contiguous block [lo, hi) of the global frame indices owned by `rank`; blocks differ by <= 1."""
+    base, rem = divmod(total_frames, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def timed_region(run_fn, steps, warmup, dist=None, device_sync=None, reduce_device=None):
+    """warmup untimed steps, then `steps` steps bracketed by barrier + device sync on both sides.
+    Returns the MAX over ranks of the elapsed seconds (what the whole job waited for)."""
+    def fence():
+        if device_sync:
+            device_sync()
+        if dist is not None:
+            dist.barrier()
+        if device_sync:
+            device_sync()
+
+    if warmup:
+        run_fn(warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run_fn(steps, 1 << 20)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device=reduce_device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def aggregate_fps(steps_per_rank, world, seconds):
+    """Whole-job throughput: every rank processed steps_per_rank frames (weak scaling)."""
+    return steps_per_rank * world / seconds

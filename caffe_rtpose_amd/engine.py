@@ -79,6 +79,62 @@ def format_json(joints, num_people, num_parts, frame_scale):
     return buf.raw[:n]
 
 
+def _u8(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_ubyte))
+
+
+def resize_area(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((dh, dw, 3), np.uint8)
+    rc = lib.rtp_resize_area(_u8(img), img.shape[1], img.shape[0], _u8(out), dw, dh)
+    if rc:
+        raise RtpError(rc, "resize_area")
+    return out
+
+
+def warp_display(img, disp_w, disp_h):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((disp_h, disp_w, 3), np.uint8)
+    s = C.c_double()
+    rc = lib.rtp_warp_display(_u8(img), img.shape[1], img.shape[0], _u8(out), disp_w, disp_h, C.byref(s))
+    if rc:
+        raise RtpError(rc, "warp_display")
+    return out, s.value
+
+
+def preprocess_frame(img, disp_w, disp_h, net_w, net_h, num_scales=1, start_scale=1.0, scale_gap=0.3):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((num_scales, 3, net_h, net_w), np.float32)
+    disp = np.empty((disp_h, disp_w, 3), np.uint8)
+    fs = C.c_float()
+    rc = lib.rtp_preprocess_frame(_u8(img), img.shape[1], img.shape[0], disp_w, disp_h, net_w, net_h, num_scales, start_scale, scale_gap,
+                                  _f(out), _u8(disp), C.byref(fs))
+    if rc:
+        raise RtpError(rc, "preprocess_frame")
+    return out, disp, fs.value
+
+
+def synth_frame(w, h, index, seed=2):
+    out = np.empty((h, w, 3), np.uint8)
+    rc = lib.rtp_synth_frame(_u8(out), w, h, index, seed)
+    if rc:
+        raise RtpError(rc, "synth_frame")
+    return out
+
+
+def load_image(path):
+    w, h = C.c_int(), C.c_int()
+    rc = lib.rtp_load_image(str(path).encode(), None, 0, C.byref(w), C.byref(h))
+    if rc:
+        raise RtpError(rc, f"cannot decode {path}")
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    rc = lib.rtp_load_image(str(path).encode(), _u8(out), out.size, C.byref(w), C.byref(h))
+    if rc:
+        raise RtpError(rc, f"cannot decode {path}")
+    return out
+
+
 def prototxt_summary(path):
     nl, nc, npart, mp, hc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
     thr = C.c_float()

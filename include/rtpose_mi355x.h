@@ -153,6 +153,23 @@ int rtp_process_and_pad_image(float* target, const unsigned char* bgr, int ow, i
  * (excluding the NUL) or RTP_ERANGE if buf is too small. frame_scale = Frame::scale. */
 long rtp_format_json(char* buf, size_t buflen, const float* joints, int num_people, int num_parts,
                      float frame_scale);
+/* Producer-side pre-processing (row a1; rtpose.cpp:322-368, 474-518).  The OpenCV primitives are
+ * restated from OpenCV's published algorithms (OpenCV is absent here and unpinned by the
+ * reference): rtp_warp_display = warpAffine(M = diag(fit scale), INTER_CUBIC, BORDER_CONSTANT 0),
+ * rtp_resize_area = cv::resize(INTER_AREA); rtp_preprocess_frame = the whole producer step ->
+ * net input (num_scales x 3 x net_h x net_w) + Frame::scale. */
+double rtp_display_fit_scale(int ow, int oh, int disp_w, int disp_h);
+int rtp_resize_area(const unsigned char* bgr, int sw, int sh, unsigned char* out, int dw, int dh);
+int rtp_warp_display(const unsigned char* bgr, int sw, int sh, unsigned char* out, int disp_w, int disp_h,
+                     double* scale_out);
+int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h,
+                         int num_scales, double start_scale, double scale_gap, float* net_input,
+                         unsigned char* display_bgr, float* frame_scale);
+/* Image files decodable without OpenCV: binary PPM (P6) and 24-bit BMP -> BGR HWC.  out_bgr may be
+ * NULL to query the size.  rtp_synth_frame: frame `index` of the procedural test video. */
+int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h);
+int rtp_synth_frame(unsigned char* out_bgr, int w, int h, int index, uint64_t seed);
+
 /* Parse a deploy prototxt and report the graph it describes (for tests / tools). */
 int rtp_prototxt_summary(const char* path, int* num_layers, int* num_conv, int* num_parts,
                          int* max_peaks, float* nms_threshold, int* heat_channels);

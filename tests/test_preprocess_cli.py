@@ -1,0 +1,132 @@
+"""Row a1 (producer-side pre-processing) and the rtpose.bin CLI.  The OpenCV primitives are restated
+(OpenCV absent, unpinned by the reference): these tests check them against exact-area / identity
+properties, not against OpenCV."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "caffe_rtpose_amd", "rtpose.bin")
+
+
+def _exact_area(img, dw, dh):
+    """Area-weighted mean of the source pixels each destination pixel covers, in float64."""
+    sh, sw, _ = img.shape
+
+    def weights(s, d):
+        W = np.zeros((d, s))
+        sc = s / d
+        for i in range(d):
+            a, b = i * sc, (i + 1) * sc
+            for j in range(int(np.floor(a)), min(int(np.ceil(b)), s)):
+                W[i, j] = max(0.0, min(b, j + 1) - max(a, j)) / sc
+        return W
+
+    Wy, Wx = weights(sh, dh), weights(sw, dw)
+    return np.einsum("ij,jkc,lk->ilc", Wy, img.astype(np.float64), Wx)
+
+
+def test_resize_area_matches_exact_area_integration():
+    import caffe_rtpose_amd as r
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (72, 128, 3)).astype(np.uint8)
+    for dw, dh in [(64, 36), (48, 32), (66, 37), (128, 72)]:
+        got = r.resize_area(img, dw, dh).astype(np.float64)
+        ref = _exact_area(img, dw, dh)
+        assert np.abs(got - ref).max() <= 0.51  # round-to-nearest of the same area mean
+    const = np.full((90, 160, 3), 77, np.uint8)
+    assert (r.resize_area(const, 82, 46) == 77).all()
+    # the net's own geometry: 1280x720 display -> 656x368 (rtpose.cpp:358-366)
+    big = rs.randint(0, 256, (720, 1280, 3)).astype(np.uint8)
+    out = r.resize_area(big, 656, 368)
+    assert out.shape == (368, 656, 3)
+    assert abs(float(out.mean()) - float(big.mean())) < 0.5
+
+
+def test_warp_display_scale_and_border():
+    import caffe_rtpose_amd as r
+    rs = np.random.RandomState(1)
+    img = rs.randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    same, s = r.warp_display(img, 64, 48)
+    assert s == 1.0 and np.array_equal(same, img)                 # scale 1: cubic at integer positions is identity
+    out, s = r.warp_display(img, 128, 120)                        # fit: limited by width -> 2x, black band below
+    assert s == 2.0 and (out[100:] == 0).all()                     # cubic taps reach 2 source rows past the edge
+    assert np.array_equal(out[0:96:2, 0:128:2], img)              # even output pixels sample source pixels exactly
+    assert r.lib.rtp_display_fit_scale(640, 480, 1280, 720) == 1.5  # BASELINE config 1
+
+
+def test_preprocess_frame_layout():
+    import caffe_rtpose_amd as r
+    img = r.synth_frame(640, 480, 3, seed=1)
+    x, disp, fs = r.preprocess_frame(img, 1280, 720, 656, 368, num_scales=3, start_scale=1.0, scale_gap=0.15)
+    assert x.shape == (3, 3, 368, 656) and disp.shape == (720, 1280, 3) and fs == 1.5
+    # scale i is centred and zero padded (rtpose.cpp:244-268): crop sizes 656x368, 560x320, 464x272
+    for i, (tw, th) in enumerate([(656, 368), (560, 320), (464, 272)]):
+        pw, ph = (656 - tw) // 2, (368 - th) // 2
+        assert (x[i, :, :ph, :] == 0).all() and (x[i, :, :, :pw] == 0).all()
+        inner = x[i, :, ph:ph + th, pw:pw + tw]
+        assert inner.min() >= -0.5 and inner.max() < 0.5
+        assert np.array_equal(inner, r.process_and_pad_image(r.resize_area(disp, tw, th), tw, th, 1))
+    with pytest.raises(r.RtpError):
+        r.preprocess_frame(img, 1280, 720, 656, 368, num_scales=1, start_scale=1.2)  # CHECK_LE(target_width, NET_RESOLUTION_WIDTH)
+
+
+def test_ppm_and_bmp_loaders(tmp_path):
+    import caffe_rtpose_amd as r
+    rs = np.random.RandomState(2)
+    bgr = rs.randint(0, 256, (5, 7, 3)).astype(np.uint8)
+    with open(tmp_path / "a.ppm", "wb") as f:
+        f.write(b"P6\n# comment\n7 5\n255\n" + bgr[:, :, ::-1].tobytes())
+    assert np.array_equal(r.load_image(tmp_path / "a.ppm"), bgr)
+    stride = (7 * 3 + 3) & ~3
+    rows = b"".join(bgr[y].tobytes() + b"\0" * (stride - 21) for y in range(4, -1, -1))
+    hdr = b"BM" + (54 + len(rows)).to_bytes(4, "little") + b"\0\0\0\0" + (54).to_bytes(4, "little")
+    hdr += (40).to_bytes(4, "little") + (7).to_bytes(4, "little") + (5).to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little")
+    hdr += (0).to_bytes(4, "little") + len(rows).to_bytes(4, "little") + b"\0" * 16
+    open(tmp_path / "b.bmp", "wb").write(hdr + rows)
+    assert np.array_equal(r.load_image(tmp_path / "b.bmp"), bgr)
+    open(tmp_path / "c.jpg", "wb").write(b"\xff\xd8\xff\xe0junk")
+    with pytest.raises(r.RtpError):
+        r.load_image(tmp_path / "c.jpg")
+
+
+def test_cli_flag_errors_and_no_device_exit_code(tmp_path):
+    assert os.path.exists(BIN), "build rtpose.bin first (__graft_entry__.build())"
+    assert subprocess.run([BIN, "--help"], capture_output=True).returncode == 0
+    p = subprocess.run([BIN, "--bogus_flag", "1"], capture_output=True)
+    assert p.returncode == 1 and b"unknown command line flag" in p.stderr
+    p = subprocess.run([BIN, "--resolution", "abc", "--video", "synthetic:64x48:1"], capture_output=True)
+    assert p.returncode == 1 and b"resolution format" in p.stderr
+    p = subprocess.run([BIN], capture_output=True)
+    assert p.returncode == 1 and b"camera" in p.stderr
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([BIN, "--video", "synthetic:64x48:2", "--model", "coco", "--net_resolution", "64x48",
+                            "--write_json", str(tmp_path / "js")], capture_output=True)
+        assert p.returncode == 1 and b"no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_json_matches_library_path(tmp_path):
+    """rtpose.bin on a synthetic video writes, for every frame, exactly the JSON the library path
+    produces for the same frame (and that the oracle's writer produces from the same joints)."""
+    import caffe_rtpose_amd as r
+    import _oracle as orc
+    out = tmp_path / "js"
+    p = subprocess.run([BIN, "--video", "synthetic:640x480:6:5", "--model", "coco", "--net_resolution", "160x96", "--resolution", "320x240",
+                        "--num_scales", "2", "--scale_gap", "0.25", "--write_json", str(out), "--no_frame_drops", "--no_display", "--num_gpu", "1"],
+                       capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    files = sorted(os.listdir(out))
+    assert files == [f"frame{i:06d}.json" for i in range(6)]
+    e = r.Engine(r.Config(net_w=160, net_h=96, num_scales=2, scale_gap=0.25, disp_w=320, disp_h=240, frames_in_flight=1))
+    for i in range(6):
+        img = r.synth_frame(640, 480, i, seed=5)
+        x, _, fs = r.preprocess_frame(img, 320, 240, 160, 96, 2, 1.0, 0.25)
+        d = e.forward_debug(x)
+        want = r.format_json(d["joints"], d["num_people"], 18, fs)
+        assert want == orc.write_json(d["joints"], d["num_people"], 18, fs)
+        assert open(out / files[i], "rb").read() == want
+    e.close()
