@@ -82,6 +82,7 @@ SIGNATURES = {
     "rtp_write_builtin_prototxt": (C.c_int, [C.c_int, C.c_char_p]),
     "rtp_caffemodel_layer": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_long), C.POINTER(C.c_long), fp]),
     "rtp_plan_summary": (C.c_long, [C.POINTER(rtp_config), C.c_char_p, C.c_size_t]),
+    "rtp_kernel_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "rtp_bench_dominant_conv": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_double)]),
 }
 

@@ -85,6 +85,8 @@ struct Ctx {
   int* num_people = nullptr;
   float* host_out = nullptr;  // pinned: [1 int as float slot][joints]
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> dom_a, dom_b;  // around every dominant-class conv launch (when timing is on)
+  int dom_used = 0;
   uint64_t tag = 0;
   bool busy = false;
 };
@@ -121,6 +123,9 @@ struct rtp_engine {
   float last_ms[5] = {0, 0, 0, 0, 0};
   std::string err;
   int dominant_step = -1;
+  bool time_dominant = false;
+  double dom_ms_total = 0;
+  long dom_launches = 0;
 };
 
 namespace {
@@ -553,15 +558,38 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
 }  // namespace
 
 namespace {
+bool is_dominant_class(const rtp_engine* e, const Step& s) {
+  if (s.type != 1 || e->dominant_step < 0) return false;
+  const ConvOp& a = e->convs[s.a];
+  const ConvOp& d = e->convs[e->steps[e->dominant_step].a];
+  return a.k == d.k && a.cin == d.cin && a.cout == d.cout && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
+}
+
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev) {
   const std::vector<PoolOp>& pools = e->pools;
+  cx.dom_used = 0;
   for (auto& s : e->steps) {
     if (s.type == 0) {
       const Tensor& t = e->tensors[0];
       HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, e->geom[0], t.Cp, cx.stream));
     } else if (s.type == 1) {
+      const bool timed = e->time_dominant && is_dominant_class(e, s);
+      if (timed) {
+        if ((int)cx.dom_a.size() <= cx.dom_used) {
+          hipEvent_t a, b;
+          HIPCHK(e, hipEventCreate(&a));
+          HIPCHK(e, hipEventCreate(&b));
+          cx.dom_a.push_back(a);
+          cx.dom_b.push_back(b);
+        }
+        HIPCHK(e, hipEventRecord(cx.dom_a[cx.dom_used], cx.stream));
+      }
       const int rc = launch_conv_step(e, cx, s);
       if (rc) return rc;
+      if (timed) {
+        HIPCHK(e, hipEventRecord(cx.dom_b[cx.dom_used], cx.stream));
+        cx.dom_used++;
+      }
     } else {
       const PoolOp& p = pools[s.a];
       const Tensor& ti = e->tensors[p.in_tensor];
@@ -663,6 +691,8 @@ void free_ctx(Ctx& cx) {
   if (cx.host_in) (void)hipHostFree(cx.host_in);
   if (cx.host_out) (void)hipHostFree(cx.host_out);
   for (int i = 0; i < 6; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
+  for (auto ev : cx.dom_a) (void)hipEventDestroy(ev);
+  for (auto ev : cx.dom_b) (void)hipEventDestroy(ev);
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
   cx = Ctx();
 }
@@ -897,6 +927,12 @@ int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) {
   int n;
   memcpy(&n, cx.host_out, sizeof(int));
   if (tag) *tag = cx.tag;
+  if (e->time_dominant) {
+    for (int i = 0; i < cx.dom_used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, cx.dom_a[i], cx.dom_b[i]) == hipSuccess) { e->dom_ms_total += ms; e->dom_launches++; }
+    }
+  }
   for (int i = 0; i < 5; ++i) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, cx.ev[i == 4 ? 0 : i], cx.ev[i == 4 ? 5 : i + 1]);
@@ -1250,6 +1286,26 @@ long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
   if (str.size() + 1 > buflen) return RTP_ERANGE;
   memcpy(buf, str.c_str(), str.size() + 1);
   return (long)str.size();
+}
+
+int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch) {
+  if (!e) return RTP_EINVAL;
+  if (total_ms) *total_ms = e->dom_ms_total;
+  if (launches) *launches = e->dom_launches;
+  if (flops_per_launch) {
+    double fl = 0;
+    if (e->dominant_step >= 0) {
+      const Step& s = e->steps[e->dominant_step];
+      const Geom& g = e->geom[e->convs[s.a].level];
+      for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N; }
+    }
+    *flops_per_launch = fl;
+  }
+  if (enable >= 0) {
+    if ((enable != 0) != e->time_dominant) { e->dom_ms_total = 0; e->dom_launches = 0; }
+    e->time_dominant = enable != 0;
+  }
+  return RTP_OK;
 }
 
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch) {

@@ -339,6 +339,12 @@ class Engine:
         lib.rtp_last_stage_ms(self.h, ms)
         return dict(conv=ms[0], resize=ms[1], nms=ms[2], connect=ms[3], total=ms[4])
 
+    def kernel_timing(self, enable=-1):
+        tot, fl = C.c_double(), C.c_double()
+        n = C.c_long()
+        self._chk(lib.rtp_kernel_timing(self.h, enable, C.byref(tot), C.byref(n), C.byref(fl)))
+        return tot.value, n.value, fl.value
+
     def bench_dominant_conv(self, iters=50):
         ms = C.c_float()
         fl = C.c_double()

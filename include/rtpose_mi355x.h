@@ -184,6 +184,10 @@ int rtp_last_stage_ms(const rtp_engine* e, float ms[5]);
  * HIP events on the engine's stream; returns avg ms per launch and the algorithmic FLOPs of one
  * launch.  Used by bench.py for the roofline line. */
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch);
+/* In-situ timing of the dominant kernel class (every paired 7x7 128->128 launch of every frame):
+ * enable = 1/0 switches HIP-event bracketing of those launches on the frame's own stream on/off
+ * (resetting the totals on a change), enable < 0 only reads.  Totals are updated in rtp_collect. */
+int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch);
 
 /* Survivors of the PAF test (temp.size(), rtpose.cpp:950) and accepted connections
  * (connection_k.size(), :980) per limb for the last synchronous frame; arrays of num_limbs ints. */

@@ -130,3 +130,30 @@ def test_cli_json_matches_library_path(tmp_path):
         assert want == orc.write_json(d["joints"], d["num_people"], 18, fs)
         assert open(out / files[i], "rb").read() == want
     e.close()
+
+
+def test_cpp_net_api_mirror_compiles_and_links(tmp_path):
+    """csrc/host_api.h (rtpose::Net & friends, the names rtpose.cpp uses) builds against the C-ABI."""
+    src = tmp_path / "use.cpp"
+    src.write_text('''
+#include "caffe_rtpose_amd/csrc/host_api.h"
+int main(int argc, char**) {
+  if (argc > 100) {  // never runs: link/compile check only
+    rtpose::Net net("model/coco/pose_deploy_linevec.prototxt", rtpose::TEST, 0);
+    net.CopyTrainedLayersFrom("model/coco/pose_iter_440000.caffemodel");
+    net.blobs()[0]->Reshape({1, 3, 368, 656});
+    auto resize = net.layer_by_name<rtpose::ImResizeLayer>("resize");
+    resize->SetStartScale(1.f); resize->SetScaleGap(0.3f);
+    net.Reshape();
+    auto nms = net.layer_by_name<rtpose::NmsLayer>("nms");
+    nms->SetThreshold(0.05f);
+    net.ForwardFrom(0);
+    return nms->GetMaxPeaks() + nms->GetNumParts() + (int)net.blob_by_name("resized_map")->mutable_cpu_data()[0];
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "use"
+    subprocess.check_call(["g++", "-std=c++17", "-I", ROOT, "-o", str(exe), str(src), "-L", os.path.join(ROOT, "caffe_rtpose_amd"),
+                           "-lrtpose_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "caffe_rtpose_amd")])
+    assert subprocess.run([str(exe)]).returncode == 0
