@@ -49,63 +49,87 @@ __device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntil
   return b;
 }
 
-// Split-K reduction across the KSPLIT wave groups of a workgroup (through LDS, which must be
-// dead: callers barrier first) followed by bias + ReLU + convert + store of the interior pixels.
+// Epilogue: every wave dumps its fp32 accumulators into LDS as [kg][row][col] (the staging LDS is
+// dead: callers barrier first), then ALL 256 threads own (pixel row, 16-channel chunk) items: sum
+// the KSPLIT partials, add bias, ReLU, convert, and store 16 channels with 16-byte vector stores
+// to every destination tensor (interior pixels only; the halo stays zero).  One integer division
+// per item instead of one per element, no idle waves.
 // acc layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
                                               int kg, int wrem, int wm0, int wn0, int lane, int img, int m0, int n0) {
+  static_assert(KSPLIT * BM * BN * 4 <= 64 * 1024, "partials fit in 64 KiB of LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
-  // ---- intra-workgroup split-K reduction (staging LDS is dead after the last barrier) ----
-  if constexpr (KSPLIT > 1) {
-    float* red = (float*)smem;
-    if (kg > 0) {
+  float* red = (float*)smem;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            red[((((kg - 1) * (WM * WN) + wrem) * (TM * TN) + i * TN + j) * 16 + q) * 64 + lane] = acc[i][j][q];
-    }
-    __syncthreads();
-    if (kg > 0) return;
-#pragma unroll
-    for (int k2 = 1; k2 < KSPLIT; ++k2)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            acc[i][j][q] += red[((((k2 - 1) * (WM * WN) + wrem) * (TM * TN) + i * TN + j) * 16 + q) * 64 + lane];
-  }
-
-  // ---- epilogue: bias, ReLU, convert, store (interior pixels only; the halo stays zero) ----
-  const int Mtot = P.H * P.Wp;
-  const long img_pix0 = (long)img * P.img_pix + (long)P.halo * P.Wp;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn0 + j * 32 + lrow;
-    const bool col_ok = col < pr.Cout;
-    const float bias = col_ok ? pr.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int m = m0 + wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
-        const int y = m / P.Wp;
-        const int xp = m - y * P.Wp;
-        if (col_ok && m < Mtot && xp >= P.halo && xp < P.halo + P.W) {
-          float v = acc[i][j][q] + bias;
-          if (P.relu) v = v > 0.f ? v : 0.f;
-          const long pix = img_pix0 + m;
-          for (int d = 0; d < pr.ndst; ++d)
-            ((T*)pr.dst[d].base)[pix * pr.dst[d].cstride + pr.dst[d].coff + col] = (T)v;
-          if (pr.out_nchw)
-            pr.out_nchw[(((long)img * pr.out_C + pr.out_coff + col) * P.H + y) * P.W + (xp - P.halo)] = v;
-        }
+        const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+        const int col = wn0 + j * 32 + lrow;
+        red[(kg * BM + row) * BN + col] = acc[i][j][q];
       }
+  __syncthreads();
+
+  constexpr int CHUNKS = BN / 16;                 // 16-channel chunks per pixel row
+  constexpr int ITEMS = BM * CHUNKS;
+  constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
+  const int Mtot = P.H * P.Wp;
+  const long img_pix0 = (long)img * P.img_pix + (long)P.halo * P.Wp;
+  for (int item = threadIdx.x; item < ITEMS; item += 256) {
+    const int row = item / CHUNKS, chunk = item % CHUNKS;
+    const int m = m0 + row;
+    const int y = m / P.Wp;
+    const int xp = m - y * P.Wp;
+    const int c0 = n0 + chunk * 16;
+    if (m >= Mtot || xp < P.halo || xp >= P.halo + P.W || c0 >= pr.Cout) continue;
+    float v[16];
+    {
+      const floatx4* src = (const floatx4*)(red + row * BN + chunk * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const floatx4 t = src[u]; v[4 * u] = t[0]; v[4 * u + 1] = t[1]; v[4 * u + 2] = t[2]; v[4 * u + 3] = t[3]; }
+#pragma unroll
+      for (int k2 = 1; k2 < KSPLIT; ++k2) {
+        const floatx4* s2 = (const floatx4*)(red + (k2 * BM + row) * BN + chunk * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const floatx4 t = s2[u]; v[4 * u] += t[0]; v[4 * u + 1] += t[1]; v[4 * u + 2] += t[2]; v[4 * u + 3] += t[3]; }
+      }
+    }
+    const floatx4* bsrc = (const floatx4*)(pr.bias + c0);  // bias is padded to CoutP (multiple of 64)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const floatx4 bb = bsrc[u];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        float t = v[4 * u + e2] + bb[e2];
+        if (P.relu) t = t > 0.f ? t : 0.f;
+        v[4 * u + e2] = t;
+      }
+    }
+    const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
+    T out[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) out[u] = (T)v[u];
+    const long pix = img_pix0 + m;
+    for (int d = 0; d < pr.ndst; ++d) {
+      T* dp = (T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].coff + c0;
+      if (nvalid == 16 && (((size_t)dp) & 15) == 0) {
+#pragma unroll
+        for (int u = 0; u < 16 / VEC; ++u) {
+          uint4 pk;
+          __builtin_memcpy(&pk, &out[u * VEC], 16);
+          ((uint4*)dp)[u] = pk;
+        }
+      } else {
+        for (int u = 0; u < nvalid; ++u) dp[u] = out[u];
+      }
+    }
+    if (pr.out_nchw) {
+      float* op = pr.out_nchw + (((long)img * pr.out_C + pr.out_coff + c0) * P.H + y) * P.W + (xp - P.halo);
+      const long plane = (long)P.H * P.W;
+      for (int u = 0; u < nvalid; ++u) op[u * plane] = v[u];
     }
   }
 }

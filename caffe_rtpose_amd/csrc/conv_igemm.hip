@@ -47,7 +47,7 @@ struct ConvTraits {
   static constexpr int TM = BM / WM / 32;
   static constexpr int TN = BN / WN / 32;
   static constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;
-  static constexpr int RED_BYTES = (KSPLIT - 1) * WM * WN * TM * TN * 16 * 64 * 4;
+  static constexpr int RED_BYTES = KSPLIT * BM * BN * 4;  // epilogue: all partials as [kg][row][col] fp32
   static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   static_assert(WM * WN * KSPLIT == 4, "4 waves per workgroup");
   static_assert(G % KSPLIT == 0, "k-groups must split evenly");

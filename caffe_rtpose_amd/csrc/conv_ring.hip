@@ -50,14 +50,13 @@ struct RingTraits {
   static constexpr int TM = BM / WM / 32;
   static constexpr int TN = BN / WN / 32;
   static constexpr int STAGE_BYTES = 2 * A_BYTES + SB * B_BYTES;
-  static constexpr int RED_BYTES = (KSPLIT - 1) * WM * WN * TM * TN * 16 * 64 * 4;
+  static constexpr int RED_BYTES = KSPLIT * BM * BN * 4;  // epilogue: all partials as [kg][row][col] fp32
   static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   static_assert(WM * WN * KSPLIT == 4, "4 waves");
   static_assert(G % KSPLIT == 0 && GPW >= 1, "k-groups split evenly");
   static_assert(B_INSTR % 4 == 0 && B_PW >= 1, "weight tile splits evenly over the waves");
   static_assert(KS == 3 || KS == 7, "strip reuse needs k > 1");
   static_assert(SB >= 3 && (SB - 2) * B_PW + 2 * A_PW <= 63, "vmcnt is a 6-bit counter");
-  static_assert(2 * KS >= SB - 2, "at most two strips may be in flight (double-buffered strip)");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -126,20 +125,28 @@ __device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
 
-// vmcnt to wait for at the top of step t (tap s of a strip): the number of DMA instructions this
-// wave may leave in flight.  Issue order inside a step: [strip of the NEXT filter row, if s == 0],
-// then the weight tile of step t+SB-1.
-//  (1) weight tile t was issued at step t-(SB-1).  Younger than it: the tiles of steps
-//      t-(SB-2)..t-1 and one strip for every such step u with s(u) == 0 (in the first strip of
-//      the kernel only steps u >= 0 exist).
-//  (2) at s == 0 the strip of THIS filter row is needed too; it was issued at step t-KS (or in
-//      the prologue, ahead of everything).  Younger than it: the KS weight tiles of steps
-//      t-KS..t-1.  For KS >= SB-1 condition (1) already implies (2).
+// Pipeline (P = the tap whose fragments are being PREFETCHED, tap P-1 is being multiplied):
+//   prologue : DMA strip 0, strip 1, weight tiles 0..SB-1; wait tile 0; read fragments(0)
+//   iteration P = 1..T-1:
+//       wait (counted) for tile P [+ its strip when s(P) == 0], lgkmcnt(0), s_barrier
+//         -> every wave has finished READING tile P-1 (its fragments sit in registers), so that
+//            ring stage and the strip buffer of the previous filter row are free
+//       DMA [strip of filter row sc(P)+1, if s(P) == 0], then weight tile P-1+SB (dummy past the end)
+//       ds_read fragments(P) -> next        } the LDS latency of tap P hides under
+//       MFMAs of tap P-1 on cur; cur = next } the MFMAs of tap P-1
+//   epilogue : MFMAs of tap T-1
+// vmcnt to wait for at the top of iteration P (s = s(P), FIRST = P is in the first strip):
+//  (1) tile P was issued SB-1 iterations ago.  Younger than it: the SB-2 tiles of iterations
+//      P-(SB-2)..P-1 and one strip for every such iteration u with s(u) == 0 (an iteration issues
+//      its strip BEFORE its weight tile); in the first strip only iterations u >= 1 exist.
+//  (2) at s == 0 (from the third strip on; strips 0 and 1 are the oldest DMAs of all) the strip of
+//      this filter row is needed; it was issued KS iterations ago: younger = KS tiles.
+// SB <= KS+1 keeps "at most one strip per window" and makes FIRST the only special case.
 template <int KS, int SB, bool FIRST, int B_PW, int A_PW>
 constexpr int ring_wait_count(int s) {
   int na = 0;
   for (int d = 1; d <= SB - 2; ++d) {
-    if (FIRST && d > s) continue;
+    if (FIRST && d >= s) continue;  // iteration P-d would be <= 0 (prologue)
     int sd = s - d;
     while (sd < 0) sd += KS;
     if (sd == 0) ++na;
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
   constexpr int A_PW = TR::A_PW, B_PW = TR::B_PW, TM = TR::TM, TN = TR::TN;
   constexpr int PAD = KS / 2;
+  static_assert(SB <= KS + 1, "ring deeper than a filter row is not supported by the wait-count formula");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
   unsigned char* sB = smem + 2 * TR::A_BYTES;
@@ -187,9 +195,6 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   const unsigned char* b_ptr = (const unsigned char*)pr.w + (long)n0 * CHB;
 
   // ---- per-lane DMA source offsets (loop invariant) ---------------------------------------
-  // A strip: DMA instruction j covers rows [j*RPI, (j+1)*RPI); lane -> (row, physical chunk); the
-  // source chunk is swizzled.  This wave issues instructions j = wave*A_PW + q; q*1024 is taken
-  // out because the instruction offset re-adds it on both the global and the LDS side.
   unsigned a_voff[A_PW];
 #pragma unroll
   for (int q = 0; q < A_PW; ++q) {
@@ -202,10 +207,14 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   const unsigned sA_addr = lds_addr_of(sA) + wave * A_PW * 1024;
   const unsigned sB_addr = lds_addr_of(sB) + wave * B_PW * 1024;
 
-  auto issue_a = [&](int buf) {  // strip at a_ptr -> sA[buf]
+  int a_chunk = 0;  // chunk index of the strip a_ptr points to
+  auto issue_a = [&](int buf) {  // strip at a_ptr -> sA[buf]; advances a_ptr to the next strip
     const unsigned l = sA_addr + buf * TR::A_BYTES;
     if constexpr (A_PW <= 4) dma_group_each<A_PW>(a_ptr, a_voff, l);
     else { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<A_PW - 4>(a_ptr, a_voff + 4, l + 4096); }
+    // past the last strip this keeps walking: harmless dummy reads of arena memory (tail pad)
+    if (++a_chunk == nchunk) { a_chunk = 0; a_ptr += row_step_bytes - (long)(nchunk - 1) * CHB; }
+    else a_ptr += CHB;
   };
   auto issue_b = [&](int stage) {  // tile at b_ptr -> sB[stage]; advances b_ptr
     const unsigned l = sB_addr + stage * TR::B_BYTES;
@@ -223,22 +232,58 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   const int nstrips = KS * nchunk;
-
-  // ---- prologue: strip 0, weight tiles 0..SB-2 ---------------------------------------------
-  issue_a(0);
-#pragma unroll
-  for (int i = 0; i < SB - 1; ++i) issue_b(i);
-  int ist = SB - 1;   // ring stage the next weight tile goes to
-  int st = 0;         // ring stage of the current step
-  int abuf = 0;
-  int chunk = 0;
-
   const int brow0 = wn0 + lrow;
   const int bswz = ring_swz<CHB>(brow0);
   const unsigned char* pb_lane = sB + brow0 * CHB;
   const int arow_base = wm0 + lrow;
 
-  // one tap: wait for its weight tile (+strip), barrier, refill the ring, 2*GPW*... MFMAs
+  uint4 fa[GPW][TM], fb[GPW][TN];      // fragments of the tap being multiplied
+  uint4 na_[GPW][TM], nb_[GPW][TN];    // fragments of the tap being prefetched
+  auto read_frags = [&](int s, int abuf, int stage, uint4 (&ra)[GPW][TM], uint4 (&rb)[GPW][TN]) {
+    const int arow = arow_base + s;
+    const int aswz = ring_swz<CHB>(arow);
+    const unsigned char* pa = sA + abuf * TR::A_BYTES + arow * CHB;
+    const unsigned char* pb = pb_lane + stage * TR::B_BYTES;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int cl = 2 * (kg * GPW + gi) + lhalf;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ra[gi][i] = *(const uint4*)(pa + i * 32 * CHB + ((cl ^ aswz) * 16));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) rb[gi][j] = *(const uint4*)(pb + j * 32 * CHB + ((cl ^ bswz) * 16));
+    }
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[gi][i], fb[gi][j], acc[i][j]);
+  };
+  auto rotate = [&]() {
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[gi][i] = na_[gi][i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[gi][j] = nb_[gi][j];
+    }
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------
+  issue_a(0);
+  issue_a(1);
+#pragma unroll
+  for (int i = 0; i < SB; ++i) issue_b(i);
+  wait_vmcnt<(SB - 1) * B_PW>();  // strips 0,1 and tile 0 are the oldest
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, 0, 0, fa, fb);
+  int abuf = 0;   // strip buffer of the tap being prefetched
+  int st = 1;     // ring stage of the tap being prefetched (P % SB)
+  int ist = 0;    // ring stage the next weight tile goes to ((P-1) % SB)
+
   auto step = [&](auto s_tag, auto first_tag) {
     constexpr int s = decltype(s_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -246,49 +291,38 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr (s == 0) {
-      // next strip (past the end: a harmless dummy read of arena memory keeps vmcnt uniform)
-      if (++chunk == nchunk) { chunk = 0; a_ptr += row_step_bytes - (long)(nchunk - 1) * CHB; }
-      else a_ptr += CHB;
-      issue_a(abuf ^ 1);
+      abuf ^= 1;          // tap P opens a new filter row: its strip is in the other buffer,
+      issue_a(abuf ^ 1);  // and the previous row's buffer is free for the row after this one
     }
     issue_b(ist);
     ist = (ist + 1 == SB) ? 0 : ist + 1;
-    {
-      const int arow = arow_base + s;
-      const int aswz = ring_swz<CHB>(arow);
-      const unsigned char* pa = sA + abuf * TR::A_BYTES + arow * CHB;
-      const unsigned char* pb = pb_lane + st * TR::B_BYTES;
-#pragma unroll
-      for (int gi = 0; gi < GPW; ++gi) {
-        const int cl = 2 * (kg * GPW + gi) + lhalf;
-        uint4 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(pa + i * 32 * CHB + ((cl ^ aswz) * 16));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(pb + j * 32 * CHB + ((cl ^ bswz) * 16));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-      }
-    }
+    read_frags(s, abuf, st, na_, nb_);
     st = (st + 1 == SB) ? 0 : st + 1;
-  };
-  auto strip = [&](auto first_tag) {
-    step(std::integral_constant<int, 0>{}, first_tag);
-    step(std::integral_constant<int, 1>{}, first_tag);
-    step(std::integral_constant<int, 2>{}, first_tag);
-    if constexpr (KS == 7) {
-      step(std::integral_constant<int, 3>{}, first_tag);
-      step(std::integral_constant<int, 4>{}, first_tag);
-      step(std::integral_constant<int, 5>{}, first_tag);
-      step(std::integral_constant<int, 6>{}, first_tag);
-    }
-    abuf ^= 1;
+    mma_all();
+    rotate();
   };
 
-  strip(std::true_type{});
-  for (int sc = 1; sc < nstrips; ++sc) strip(std::false_type{});
+  // first strip: taps 1..KS-1 (tap 0 was read in the prologue)
+  step(std::integral_constant<int, 1>{}, std::true_type{});
+  step(std::integral_constant<int, 2>{}, std::true_type{});
+  if constexpr (KS == 7) {
+    step(std::integral_constant<int, 3>{}, std::true_type{});
+    step(std::integral_constant<int, 4>{}, std::true_type{});
+    step(std::integral_constant<int, 5>{}, std::true_type{});
+    step(std::integral_constant<int, 6>{}, std::true_type{});
+  }
+  for (int sc = 1; sc < nstrips; ++sc) {
+    step(std::integral_constant<int, 0>{}, std::false_type{});
+    step(std::integral_constant<int, 1>{}, std::false_type{});
+    step(std::integral_constant<int, 2>{}, std::false_type{});
+    if constexpr (KS == 7) {
+      step(std::integral_constant<int, 3>{}, std::false_type{});
+      step(std::integral_constant<int, 4>{}, std::false_type{});
+      step(std::integral_constant<int, 5>{}, std::false_type{});
+      step(std::integral_constant<int, 6>{}, std::false_type{});
+    }
+  }
+  mma_all();  // last tap
 
   // drain the dummy DMAs before LDS is reused / the workgroup exits
   wait_vmcnt<0>();
@@ -320,8 +354,10 @@ template <typename T, int KS>
 static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int nprob, int N, hipStream_t stream) {
   if (chb == 256) {
     if (cfg == CFG_64x64) {
-      if (P.ring_sb == 4) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 4>(P, nprob, N, stream);
-      return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 6>(P, nprob, N, stream);
+      if constexpr (KS == 7) {
+        if (P.ring_sb != 4) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 6>(P, nprob, N, stream);
+      }
+      return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 4>(P, nprob, N, stream);
     }
     return hipErrorInvalidValue;
   }
@@ -329,7 +365,9 @@ static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int npr
   switch (cfg) {
     case CFG_128x128: return ring_launch_one<T, 128, 128, 2, 2, 1, KS, 128, 4>(P, nprob, N, stream);
     case CFG_64x128: return ring_launch_one<T, 64, 128, 1, 2, 2, KS, 128, 4>(P, nprob, N, stream);
-    case CFG_64x64: return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 6>(P, nprob, N, stream);
+    case CFG_64x64:
+      if constexpr (KS == 7) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 6>(P, nprob, N, stream);
+      else return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 4>(P, nprob, N, stream);
     case CFG_128x64: return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);
     default: return hipErrorInvalidValue;
   }

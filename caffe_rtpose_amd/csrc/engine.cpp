@@ -549,6 +549,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
     P.xcdmap = (xm && xm[0] == '0') ? 0 : 1;
     static const char* sb = getenv("RTP_RING_SB");
     P.ring_sb = (sb && sb[0] == '4') ? 4 : 6;
+    static const char* ab = getenv("RTP_RING_ABLATE");
+    P.ablate = ab ? atoi(ab) : 0;
   }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));

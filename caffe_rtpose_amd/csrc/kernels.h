@@ -48,6 +48,7 @@ struct ConvParams {
   int rotate;  // ring kernel: rotate the filter-row order per tile (speed only)
   int xcdmap;  // 1: contiguous logical range per XCD (decode_block), 0: dispatch order
   int ring_sb; // ring depth request (4 or 6) where both are instantiated
+  int ablate;  // profiling only: bit0 skip in-loop DMA, bit1 skip MFMAs, bit2 skip fragment reads, bit3 skip barrier
 };
 
 // which tile configuration a conv launch uses
