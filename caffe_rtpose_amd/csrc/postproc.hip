@@ -312,48 +312,98 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
     __syncthreads();
   }
   const int nc = running;
-  // ---- phase 2: rank sort (unique order) or exact replica (ties) ----
+  // ---- phase 2: STABLE parallel rank sort: position = #greater + #equal-with-smaller-index.
+  // For distinct scores this is the unique sorted order; equal scores are handled in phase 3.
   for (int i = tid; i < nc; i += 256) {
     const float ki = cands[i].score;
-    int rank = 0, eq = 0;
-    if (!(ki == ki)) eq = 2;  // NaN
+    int rank = 0;
+    bool nan = !(ki == ki);
     for (int j = 0; j < nc; ++j) {
       const float kj = cands[j].score;
-      rank += (kj > ki) ? 1 : 0;
-      eq += (kj == ki) ? 1 : 0;
+      rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
     }
-    if (eq != 1) tie = 1;
+    if (nan) tie = 2;  // NaN breaks the ordering: force the exact path
     else sorted[rank] = cands[i];
   }
   __syncthreads();
-  if (tid != 0) return;
-  if (err) { *p.num_people = CONNECT_ERR_RANGE; }
-  p.cand_count[k] = nc;
-  const Cand* order = sorted;
-  if (tie) {
-    std_sort_replica(cands, nc);
-    order = cands;
-  }
+  if (wave != 0) return;
+  // ---- phase 3 (wave 0): greedy assignment (:956-980), 64 sorted rows per step.
+  // std::sort leaves the relative order of EQUAL scores implementation-defined, but that order only
+  // matters if two tied candidates are both still free (i and j unused) when the scan reaches
+  // them.  The scan detects exactly that case and only then falls back to the libstdc++ replica.
   const int num = nA < nB ? nA : nB;
-  int cnt = 0;
-  unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};  // up to 256 peaks per part
   int* conn = p.conn + (long)k * p.max_peaks * 2;
   float* cs = p.conn_score + (long)k * p.max_peaks;
-  for (int row = 0; row < nc; ++row) {
-    if (cnt == num) break;
-    const Cand c = order[row];
-    const int i = c.ij >> 16, j = c.ij & 0xffff;
-    const unsigned long long ba = 1ull << ((i - 1) & 63), bb = 1ull << ((j - 1) & 63);
-    if (!(occA[(i - 1) >> 6] & ba) && !(occB[(j - 1) >> 6] & bb)) {
-      conn[cnt * 2] = limbSeq[2 * k] * peaks_offset + i * 3 + 2;
-      conn[cnt * 2 + 1] = limbSeq[2 * k + 1] * peaks_offset + j * 3 + 2;
-      cs[cnt] = c.score;
-      cnt++;
-      occA[(i - 1) >> 6] |= ba;
-      occB[(j - 1) >> 6] |= bb;
+  const int partA_off = limbSeq[2 * k] * peaks_offset, partB_off = limbSeq[2 * k + 1] * peaks_offset;
+  bool ambiguous = (tie == 2);
+  int cnt = 0;
+  if (!ambiguous) {
+    unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};  // wave-uniform copies
+    for (int base = 0; base < nc && cnt < num && !ambiguous; base += 64) {
+      const int row = base + lane;
+      Cand c; c.score = 0.f; c.ij = 0x00010001;
+      if (row < nc) c = sorted[row];
+      const int i = c.ij >> 16, j = c.ij & 0xffff;
+      unsigned long long done = 0;  // lanes of this chunk already decided
+      while (cnt < num) {
+        const bool free_ = row < nc && !((done >> lane) & 1) && !((occA[(i - 1) >> 6] >> ((i - 1) & 63)) & 1) &&
+                           !((occB[(j - 1) >> 6] >> ((j - 1) & 63)) & 1);
+        const unsigned long long bal = __ballot(free_);
+        if (!bal) break;
+        const int first = __ffsll((long long)bal) - 1;
+        const float sc = __shfl(c.score, first);
+        const int wi = __shfl(i, first), wj = __shfl(j, first);
+        // any OTHER free row with the same score (later in this chunk or in the following rows)?
+        bool amb = __any(free_ && lane != first && c.score == sc);
+        if (!amb) {
+          // tied rows may continue past this chunk
+          for (int r2 = base + 64; r2 < nc; ++r2) {
+            const Cand t2 = sorted[r2];
+            if (!(t2.score == sc)) break;
+            const int i2 = t2.ij >> 16, j2 = t2.ij & 0xffff;
+            if (!((occA[(i2 - 1) >> 6] >> ((i2 - 1) & 63)) & 1) && !((occB[(j2 - 1) >> 6] >> ((j2 - 1) & 63)) & 1)) { amb = true; break; }
+          }
+        }
+        if (amb) { ambiguous = true; break; }
+        if (lane == 0) {
+          conn[cnt * 2] = partA_off + wi * 3 + 2;
+          conn[cnt * 2 + 1] = partB_off + wj * 3 + 2;
+          cs[cnt] = sc;
+        }
+        cnt++;
+        occA[(wi - 1) >> 6] |= 1ull << ((wi - 1) & 63);
+        occB[(wj - 1) >> 6] |= 1ull << ((wj - 1) & 63);
+        done |= (2ull << first) - 1ull;  // rows up to and including `first` are decided
+      }
     }
   }
-  p.conn_count[k] = cnt;
+  if (ambiguous) {
+    if (lane == 0) {
+      std_sort_replica(cands, nc);
+      cnt = 0;
+      unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};
+      for (int row = 0; row < nc; ++row) {
+        if (cnt == num) break;
+        const Cand c = cands[row];
+        const int i = c.ij >> 16, j = c.ij & 0xffff;
+        const unsigned long long ba = 1ull << ((i - 1) & 63), bb = 1ull << ((j - 1) & 63);
+        if (!(occA[(i - 1) >> 6] & ba) && !(occB[(j - 1) >> 6] & bb)) {
+          conn[cnt * 2] = partA_off + i * 3 + 2;
+          conn[cnt * 2 + 1] = partB_off + j * 3 + 2;
+          cs[cnt] = c.score;
+          cnt++;
+          occA[(i - 1) >> 6] |= ba;
+          occB[(j - 1) >> 6] |= bb;
+        }
+      }
+    }
+    cnt = __shfl(cnt, 0);
+  }
+  if (lane == 0) {
+    if (err) *p.num_people = CONNECT_ERR_RANGE;
+    p.cand_count[k] = nc | (ambiguous ? (1 << 30) : 0);  // bit 30: the exact-tie path ran (diagnostics only)
+    p.conn_count[k] = cnt;
+  }
 }
 
 // Person assembly (rtpose.cpp:982-1046 / :684-722) + emission (:1051-1073 / :726-748).

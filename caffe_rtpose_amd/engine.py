@@ -303,7 +303,7 @@ class Engine:
         a = (C.c_int * nl)()
         b = (C.c_int * nl)()
         self._chk(lib.rtp_debug_connect_stats(self.h, a, b))
-        return list(a), list(b)
+        return [v & ((1 << 30) - 1) for v in a], list(b), [v >> 30 for v in a]
 
     # ---- weights
     def conv_layers(self):
