@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--num_scales", type=int, default=1)
     ap.add_argument("--scale_gap", type=float, default=0.3)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
-    ap.add_argument("--in_flight", type=int, default=4)
+    ap.add_argument("--in_flight", type=int, default=8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 

@@ -159,8 +159,8 @@ constexpr int ring_wait_count(int s) {
   return n;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_>
-__global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
   constexpr int A_PW = TR::A_PW, B_PW = TR::B_PW, TM = TR::TM, TN = TR::TN;
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   auto issue_a = [&](int buf) {  // strip at a_ptr -> sA[buf]; advances a_ptr to the next strip
     const unsigned l = sA_addr + buf * TR::A_BYTES;
     if constexpr (A_PW <= 4) dma_group_each<A_PW>(a_ptr, a_voff, l);
-    else { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<A_PW - 4>(a_ptr, a_voff + 4, l + 4096); }
+    else if constexpr (A_PW <= 8) { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<A_PW - 4>(a_ptr, a_voff + 4, l + 4096); }
+    else { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<4>(a_ptr, a_voff + 4, l + 4096); dma_group_each<A_PW - 8>(a_ptr, a_voff + 8, l + 8192); }
     // past the last strip this keeps walking: harmless dummy reads of arena memory (tail pad)
     if (++a_chunk == nchunk) { a_chunk = 0; a_ptr += row_step_bytes - (long)(nchunk - 1) * CHB; }
     else a_ptr += CHB;
@@ -298,7 +299,11 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
     ist = (ist + 1 == SB) ? 0 : ist + 1;
     read_frags(s, abuf, st, na_, nb_);
     st = (st + 1 == SB) ? 0 : st + 1;
+    // pin the order: tap P's ds_reads are ISSUED before tap P-1's MFMAs (hipcc otherwise sinks the
+    // reads to just in front of their consumers and the LDS latency is exposed twice per tap)
+    __builtin_amdgcn_sched_barrier(0);
     mma_all();
+    __builtin_amdgcn_sched_barrier(0);
     rotate();
   };
 
@@ -331,10 +336,10 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(ConvParams P) {
   conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
-  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
+  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW>;
   static std::atomic<unsigned> attr_mask{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -353,6 +358,8 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
 template <typename T, int KS>
 static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int nprob, int N, hipStream_t stream) {
   if (chb == 256) {
+    if (cfg == CFG_128x32) return ring_launch_one<T, 128, 32, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
+    if (cfg == CFG_128x64) return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
     if (cfg == CFG_64x64) {
       if constexpr (KS == 7) {
         if (P.ring_sb != 4) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 6>(P, nprob, N, stream);
@@ -366,8 +373,8 @@ static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int npr
     case CFG_128x128: return ring_launch_one<T, 128, 128, 2, 2, 1, KS, 128, 4>(P, nprob, N, stream);
     case CFG_64x128: return ring_launch_one<T, 64, 128, 1, 2, 2, KS, 128, 4>(P, nprob, N, stream);
     case CFG_64x64:
-      if constexpr (KS == 7) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 6>(P, nprob, N, stream);
-      else return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 4>(P, nprob, N, stream);
+      // 56 KiB of LDS and <= 128 registers: two workgroups (of different frames) share a CU
+      return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 4, 2>(P, nprob, N, stream);
     case CFG_128x64: return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);
     default: return hipErrorInvalidValue;
   }

@@ -373,18 +373,32 @@ int build_plan(rtp_engine* e) {
     const int nprob = s.b >= 0 ? 2 : 1;
     const int maxcout = std::max(A.cout, s.b >= 0 ? e->convs[s.b].cout : 0);
     const long M = (long)g.H * g.Wp;
+    // Tile choice.  The layers are L2->LDS bandwidth bound, so among the tiles
+    // that give every CU a workgroup (>= 224 of 256) take the one that moves the fewest bytes:
+    // per workgroup one weight tile of BN rows and 1/k of a (BM+k-1)-row strip per tap.
+    const bool ring_ok = !A.first && (A.k_eff == 3 || A.k_eff == 7);
+    const int row_bytes_all = A.Cin_p * e->elem;
     std::vector<int> cands;
     if (A.rowb == 64) cands = {CFG_128x64};
+    else if (maxcout <= 32 && ring_ok && row_bytes_all % 256 == 0) cands = {CFG_128x32, CFG_128x64, CFG_64x64};
     else if (maxcout <= 64) cands = {CFG_128x64, CFG_64x64};
+    else if (ring_ok && row_bytes_all % 256 == 0) cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64, CFG_128x32};
     else cands = {CFG_128x128, CFG_64x128, CFG_64x64};
     int best = cands.back();
     long best_wg = -1;
+    double best_bytes = 1e300;
     bool chosen = false;
     for (int cf : cands) {
       const ConvCfgInfo ci = conv_cfg_info(cf);
       const long wg = ((M + ci.BM - 1) / ci.BM) * e->N * (round_up(maxcout, ci.BN) / ci.BN) * nprob;
-      if (!chosen && wg >= 200) { best = cf; chosen = true; }
-      if (!chosen && wg > best_wg) { best = cf; best_wg = wg; }
+      const double bytes = (double)wg * (ci.BN + (double)(ci.BM + A.k_eff - 1) / A.k_eff);
+      if (wg >= 224) {
+        if (!chosen || bytes < best_bytes) { best = cf; best_bytes = bytes; chosen = true; }
+      } else if (!chosen && wg > best_wg) { best = cf; best_wg = wg; }
+    }
+    {
+      static const char* fc = getenv("RTP_FORCE_CFG");  // experiments only: force a tile for the k x k layers at 1/8 resolution
+      if (fc && ring_ok && A.level == 3 && maxcout > 64) best = atoi(fc);
     }
     const ConvCfgInfo ci = conv_cfg_info(best);
     const char* force = getenv("RTP_CONV_IMPL");
@@ -398,7 +412,8 @@ int build_plan(rtp_engine* e) {
       if (allow_ring && !c.first && (c.k_eff == 3 || c.k_eff == 7)) {
         const int row_bytes = c.Cin_p * e->elem;
         static const char* f128 = getenv("RTP_RING_CHB128");
-        int chb = (best == CFG_64x64 && row_bytes % 256 == 0 && !(f128 && f128[0] == '1')) ? 256 : 128;
+        int chb = ((best == CFG_64x64 || best == CFG_128x64 || best == CFG_128x32) && row_bytes % 256 == 0 && !(f128 && f128[0] == '1')) ? 256 : 128;
+        if (best == CFG_128x32 && chb != 256) { best = CFG_64x64; c.cfg = best; c.CoutP = round_up(maxcout, 64); chb = 128; }
         if (row_bytes % chb == 0) {
           c.impl = 1;
           c.rowb = chb;

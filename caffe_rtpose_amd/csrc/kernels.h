@@ -52,7 +52,7 @@ struct ConvParams {
 };
 
 // which tile configuration a conv launch uses
-enum ConvCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_128x64 = 3, CFG_COUNT = 4 };
+enum ConvCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_128x64 = 3, CFG_128x32 = 4, CFG_COUNT = 5 };
 
 struct ConvCfgInfo { int BM, BN; };
 inline ConvCfgInfo conv_cfg_info(int cfg) {
@@ -60,6 +60,7 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case CFG_128x128: return {128, 128};
     case CFG_64x128: return {64, 128};
     case CFG_64x64: return {64, 64};
+    case CFG_128x32: return {128, 32};
     default: return {128, 64};
   }
 }
