@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
   const BlockCoord bc = decode_block(P, P.CoutP / BN, P.tiles_per_img * P.nimg);
   const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;
+  if (P.tstamp && tid == 0) atomicMin(&P.tstamp[0], (unsigned long long)wall_clock64());
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave / (WM * WN);
@@ -334,6 +335,10 @@ __global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
   __builtin_amdgcn_s_barrier();
 
   conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
+  if (P.tstamp && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
+    atomicMax(&P.tstamp[1], (unsigned long long)wall_clock64());
+  }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>

@@ -126,6 +126,9 @@ struct rtp_engine {
   bool time_dominant = false;
   double dom_ms_total = 0;
   long dom_launches = 0;
+  unsigned long long* ts_ring = nullptr;  // device: {min start, max end} per timed launch
+  int ts_next = 0;
+  static const int TS_SLOTS = 32768;
 };
 
 namespace {
@@ -542,7 +545,7 @@ void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProbl
   pr->Cout = c.cout;
 }
 
-int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
+int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, unsigned long long* tstamp = nullptr) {
   const ConvOp& A = e->convs[s.a];
   const Geom& g = e->geom[A.level];
   ConvParams P;
@@ -556,6 +559,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s) {
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
   P.relu = A.relu ? 1 : 0;
+  P.tstamp = tstamp;
   P.nimg = e->N;
   {
     static const char* rot = getenv("RTP_CONV_ROTATE");
@@ -590,23 +594,10 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev) {
       const Tensor& t = e->tensors[0];
       HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, e->geom[0], t.Cp, cx.stream));
     } else if (s.type == 1) {
-      const bool timed = e->time_dominant && is_dominant_class(e, s);
-      if (timed) {
-        if ((int)cx.dom_a.size() <= cx.dom_used) {
-          hipEvent_t a, b;
-          HIPCHK(e, hipEventCreate(&a));
-          HIPCHK(e, hipEventCreate(&b));
-          cx.dom_a.push_back(a);
-          cx.dom_b.push_back(b);
-        }
-        HIPCHK(e, hipEventRecord(cx.dom_a[cx.dom_used], cx.stream));
-      }
-      const int rc = launch_conv_step(e, cx, s);
+      const bool timed = e->time_dominant && e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS && is_dominant_class(e, s);
+      const int rc = launch_conv_step(e, cx, s, timed ? e->ts_ring + 2 * (size_t)e->ts_next : nullptr);
       if (rc) return rc;
-      if (timed) {
-        HIPCHK(e, hipEventRecord(cx.dom_b[cx.dom_used], cx.stream));
-        cx.dom_used++;
-      }
+      if (timed) e->ts_next++;
     } else {
       const PoolOp& p = pools[s.a];
       const Tensor& ti = e->tensors[p.in_tensor];
@@ -753,6 +744,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   for (auto& c : e->ctx) free_ctx(c);
   if (e->dweights) (void)hipFree(e->dweights);
   if (e->dchmap) (void)hipFree(e->dchmap);
+  if (e->ts_ring) (void)hipFree(e->ts_ring);
   delete e;
 }
 
@@ -944,12 +936,7 @@ int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) {
   int n;
   memcpy(&n, cx.host_out, sizeof(int));
   if (tag) *tag = cx.tag;
-  if (e->time_dominant) {
-    for (int i = 0; i < cx.dom_used; ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, cx.dom_a[i], cx.dom_b[i]) == hipSuccess) { e->dom_ms_total += ms; e->dom_launches++; }
-    }
-  }
+
   for (int i = 0; i < 5; ++i) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, cx.ev[i == 4 ? 0 : i], cx.ev[i == 4 ? 5 : i + 1]);
@@ -1307,6 +1294,19 @@ long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
 
 int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch) {
   if (!e) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  // harvest the timestamp ring: every used slot holds {first workgroup start, last workgroup end}
+  if (e->ts_ring && e->ts_next > 0 && e->fifo.empty()) {
+    HIPCHK(e, hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)2 * e->ts_next);
+    HIPCHK(e, hipMemcpy(h.data(), e->ts_ring, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
+    for (int i = 0; i < e->ts_next; ++i)
+      if (h[2 * i + 1] > h[2 * i]) { e->dom_ms_total += (double)(h[2 * i + 1] - h[2 * i]) / (double)khz; e->dom_launches++; }
+    e->ts_next = 0;
+  }
   if (total_ms) *total_ms = e->dom_ms_total;
   if (launches) *launches = e->dom_launches;
   if (flops_per_launch) {
@@ -1321,6 +1321,13 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
   if (enable >= 0) {
     if ((enable != 0) != e->time_dominant) { e->dom_ms_total = 0; e->dom_launches = 0; }
     e->time_dominant = enable != 0;
+    if (e->time_dominant) {
+      if (!e->ts_ring) HIPCHK(e, hipMalloc((void**)&e->ts_ring, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
+      std::vector<unsigned long long> init((size_t)2 * rtp_engine::TS_SLOTS);
+      for (int i = 0; i < rtp_engine::TS_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+      HIPCHK(e, hipMemcpy(e->ts_ring, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+      e->ts_next = 0;
+    }
   }
   return RTP_OK;
 }

@@ -185,8 +185,10 @@ int rtp_last_stage_ms(const rtp_engine* e, float ms[5]);
  * launch.  Used by bench.py for the roofline line. */
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch);
 /* In-situ timing of the dominant kernel class (every paired 7x7 128->128 launch of every frame):
- * enable = 1/0 switches HIP-event bracketing of those launches on the frame's own stream on/off
- * (resetting the totals on a change), enable < 0 only reads.  Totals are updated in rtp_collect. */
+ * enable = 1/0 switches it on/off (resetting the totals on a change), enable < 0 only reads.  While
+ * on, each such launch records {first workgroup start, last workgroup end} of the device wall clock
+ * (what a profiler's kernel trace reports; stream events would also count the time a launch queues
+ * behind other frames' kernels).  Call with an idle engine to harvest. */
 int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch);
 
 /* Survivors of the PAF test (temp.size(), rtpose.cpp:950) and accepted connections
