@@ -37,15 +37,26 @@ __device__ __forceinline__ float cubic_interp(float v0, float v1, float v2, floa
   return (float)((((double)t1 + t2) + (double)t3) + (double)v1);
 }
 
-__global__ __launch_bounds__(256) void resize_kernel(ResizeParams p) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
+// One thread = an 8x8 block of outputs of one channel: x0 = 8k-4, y0 = 8m-4.  For the full-size
+// scale such a block shares ONE 4x4 low-res neighbourhood, so the 4 row interpolations t[i] of an
+// output column are computed once and reused by the 8 output rows (1.5 cubic evaluations per output
+// instead of 5) and the 16 neighbours are loaded once per block.  Per-output arithmetic and
+// rounding are exactly the reference kernel's; whenever the neighbourhood of an output differs
+// from the previous one (other scales, borders) it is simply recomputed.
+__global__ __launch_bounds__(128) void resize_kernel(ResizeParams p) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // 8-wide column strip
+  const int x0 = 8 * k - 4;
+  const int y0 = 8 * (int)blockIdx.y - 4;
   const int c = blockIdx.z;
-  if (x >= p.tw) return;
+  if (x0 >= p.tw) return;
   const long plane = (long)p.h * p.w;
   const float* src_c = p.src + (long)c * plane;
   const long src_offset = (long)p.C * plane;
-  float sum = 0.f;
+  float sum[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[r][j] = 0.f;
   for (int n = 0; n < p.num; ++n) {
     const int padw = (int)floorf((float)(p.w / 2) * (1 - p.start_scale + n * p.scale_gap));
     const int padh = (int)floorf((float)(p.h / 2) * (1 - p.start_scale + n * p.scale_gap));
@@ -53,39 +64,78 @@ __global__ __launch_bounds__(256) void resize_kernel(ResizeParams p) {
     const float* sp = src_c + n * src_offset;
     const float offset_x = (float)((double)(p.tw / (float)ow / 2) - 0.5);
     const float offset_y = (float)((double)(p.th / (float)oh / 2) - 0.5);
-    const float x_on = (x - offset_x) * ((float)ow / p.tw);
-    const float y_on = (y - offset_y) * ((float)oh / p.th);
-    int xn0, xn1, xn2, xn3, yn[4];
-    xn1 = (int)((double)x_on + 1e-5);
-    xn1 = (xn1 < 0) ? 0 : xn1;
-    xn0 = ((xn1 - 1 < 0) ? xn1 : (xn1 - 1)) + padw;
-    xn2 = (xn1 + 1 >= ow) ? (ow - 1) : (xn1 + 1);
-    xn3 = ((xn2 + 1 >= ow) ? (ow - 1) : (xn2 + 1)) + padw;
-    const float dx = x_on - xn1;
-    xn1 += padw;
-    xn2 += padw;
-    yn[1] = (int)((double)y_on + 1e-5);
-    yn[1] = (yn[1] < 0) ? 0 : yn[1];
-    yn[0] = ((yn[1] - 1 < 0) ? yn[1] : (yn[1] - 1)) + padh;
-    yn[2] = (yn[1] + 1 >= oh) ? (oh - 1) : (yn[1] + 1);
-    yn[3] = ((yn[2] + 1 >= oh) ? (oh - 1) : (yn[2] + 1)) + padh;
-    const float dy = y_on - yn[1];
-    yn[1] += padh;
-    yn[2] += padh;
     const int rw = ow + 2 * padw;
-    float t[4];
+    float t[4][8];   // row interpolations of the current y-neighbourhood, per output column
+    int prev_y = -1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      t[i] = cubic_interp(sp[yn[i] * rw + xn0], sp[yn[i] * rw + xn1], sp[yn[i] * rw + xn2], sp[yn[i] * rw + xn3], dx);
-    const float d = cubic_interp(t[0], t[1], t[2], t[3], dy);
-    sum = sum + d;
+    for (int r = 0; r < 8; ++r) {
+      const int y = y0 + r;
+      if (y < 0 || y >= p.th) continue;
+      const float y_on = (y - offset_y) * ((float)oh / p.th);
+      int yn1 = (int)((double)y_on + 1e-5);
+      yn1 = (yn1 < 0) ? 0 : yn1;
+      const float dy = y_on - yn1;
+      if (yn1 != prev_y) {
+        prev_y = yn1;
+        int yn[4];
+        yn[0] = ((yn1 - 1 < 0) ? yn1 : (yn1 - 1)) + padh;
+        yn[2] = (yn1 + 1 >= oh) ? (oh - 1) : (yn1 + 1);
+        yn[3] = ((yn[2] + 1 >= oh) ? (oh - 1) : (yn[2] + 1)) + padh;
+        yn[1] = yn1 + padh;
+        yn[2] += padh;
+        float v[4][4];
+        int prev_x = -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int x = x0 + j;
+          if (x < 0 || x >= p.tw) continue;
+          const float x_on = (x - offset_x) * ((float)ow / p.tw);
+          int xn1 = (int)((double)x_on + 1e-5);
+          xn1 = (xn1 < 0) ? 0 : xn1;
+          const float dx = x_on - xn1;
+          if (xn1 != prev_x) {
+            prev_x = xn1;
+            const int xn0 = ((xn1 - 1 < 0) ? xn1 : (xn1 - 1)) + padw;
+            const int xn2 = (xn1 + 1 >= ow) ? (ow - 1) : (xn1 + 1);
+            const int xn3 = ((xn2 + 1 >= ow) ? (ow - 1) : (xn2 + 1)) + padw;
+            const int xa = xn1 + padw, xb = xn2 + padw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float* rr = sp + yn[i] * rw;
+              v[i][0] = rr[xn0]; v[i][1] = rr[xa]; v[i][2] = rr[xb]; v[i][3] = rr[xn3];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i][j] = cubic_interp(v[i][0], v[i][1], v[i][2], v[i][3], dx);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int x = x0 + j;
+        if (x < 0 || x >= p.tw) continue;
+        const float d = cubic_interp(t[0][j], t[1][j], t[2][j], t[3][j], dy);
+        sum[r][j] = sum[r][j] + d;
+      }
+    }
   }
-  p.dst[((long)c * p.th + y) * p.tw + x] = sum / p.num;
+  float* o = p.dst + (long)c * p.th * p.tw;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int y = y0 + r;
+    if (y < 0 || y >= p.th) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int x = x0 + j;
+      if (x >= 0 && x < p.tw) o[(long)y * p.tw + x] = sum[r][j] / p.num;
+    }
+  }
 }
 
 hipError_t launch_resize(const ResizeParams& p, hipStream_t stream) {
-  dim3 grid((p.tw + 255) / 256, p.th, p.C);
-  hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, stream, p);
+  const int strips = (p.tw + 4 + 7) / 8;  // x0 = 8k-4 covers x in [-4, tw)
+  const int bands = (p.th + 4 + 7) / 8;   // y0 = 8m-4
+  dim3 grid((strips + 127) / 128, bands, p.C);
+  hipLaunchKernelGGL(resize_kernel, grid, dim3(128), 0, stream, p);
   return hipGetLastError();
 }
 
