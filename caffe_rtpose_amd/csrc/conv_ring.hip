@@ -65,7 +65,15 @@ struct RingTraits {
 // next step's barrier, so without it a wave could pass the barrier with ds_reads of the stage that
 // another wave is about to overwrite by DMA still in flight (seen as run-to-run differences when
 // a co-resident workgroup keeps the LDS pipeline busy).
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+// Issued through the builtin (not asm) so that hipcc's own waitcnt bookkeeping sees "all LDS reads
+// returned" and does not re-wait (lgkmcnt(k)) in front of the MFMAs that consume the previous tap's
+// fragments.  gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14].
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "6-bit vmcnt");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
+  asm volatile("" ::: "memory");
+}
 
 // LDS-DMA groups.  Issued from inline asm on purpose: hipcc cannot tell the ring stages apart, so
 // with the builtin it drains the whole DMA queue (s_waitcnt vmcnt(0)) before the first ds_read of
@@ -286,25 +294,48 @@ __global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
   int st = 1;     // ring stage of the tap being prefetched (P % SB)
   int ist = 0;    // ring stage the next weight tile goes to ((P-1) % SB)
 
+  // fragment read #idx of tap s (idx enumerates group-major: TM A-fragments then TN B-fragments)
+  auto read_one = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) {
+    const int gi = idx / (TM + TN), q = idx % (TM + TN);
+    const int cl = 2 * (kg * GPW + gi) + lhalf;
+    if (q < TM) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
+    else nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
+  };
+  auto mma_one = [&](int idx) {
+    const int gi = idx / (TM * TN), r = idx % (TM * TN);
+    Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
+  };
+  constexpr int NMMA = GPW * TM * TN, NRD = GPW * (TM + TN);
+
+  // One tap.  After the barrier the MFMAs of tap P-1 (operands already in registers) start at once
+  // and the DMA issue, the address math and tap P's ds_reads are slotted BETWEEN them, so the
+  // matrix pipe is busy while everything else issues (pinned with sched_barrier: left alone hipcc
+  // clusters the MFMAs and leaves the pipe idle during the ~150 cycles of issue in front of them).
   auto step = [&](auto s_tag, auto first_tag) {
     constexpr int s = decltype(s_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
     wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (s == 0) {
-      abuf ^= 1;          // tap P opens a new filter row: its strip is in the other buffer,
-      issue_a(abuf ^ 1);  // and the previous row's buffer is free for the row after this one
+    if constexpr (s == 0) abuf ^= 1;  // tap P opens a new filter row: its strip is in the other buffer
+    const int arow = arow_base + s;
+    const int aswz = ring_swz<CHB>(arow);
+    const unsigned char* pa = sA + abuf * TR::A_BYTES + arow * CHB;
+    const unsigned char* pb = pb_lane + st * TR::B_BYTES;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < NMMA; ++m) {
+      mma_one(m);
+      if (m == 0) {
+        if constexpr (s == 0) issue_a(abuf ^ 1);  // the previous row's buffer is free for the row after this one
+        issue_b(ist);
+      }
+#pragma unroll
+      for (int rd = m * NRD / NMMA; rd < (m + 1) * NRD / NMMA; ++rd) read_one(rd, pa, pb, aswz);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    issue_b(ist);
     ist = (ist + 1 == SB) ? 0 : ist + 1;
-    read_frags(s, abuf, st, na_, nb_);
     st = (st + 1 == SB) ? 0 : st + 1;
-    // pin the order: tap P's ds_reads are ISSUED before tap P-1's MFMAs (hipcc otherwise sinks the
-    // reads to just in front of their consumers and the LDS latency is exposed twice per tap)
-    __builtin_amdgcn_sched_barrier(0);
-    mma_all();
-    __builtin_amdgcn_sched_barrier(0);
     rotate();
   };
 
