@@ -75,15 +75,21 @@ def main():
     frames = [(torch.randint(0, 256, (args.num_scales, 3, 368, 656), generator=g).float() / 256.0 - 0.5).cuda() for _ in range(nframes)]
     torch.cuda.synchronize()
 
+    lat = []
+
     def run(nsteps, base_tag):
         sub = col = 0
         people = 0
+        t_sub = {}
         while col < nsteps:
             while sub < nsteps and eng.in_flight() < args.in_flight:
+                t_sub[sub] = time.perf_counter()
                 eng.submit_device(frames[sub % nframes].data_ptr(), tag=base_tag + sub)
                 sub += 1
             tag, n, _ = eng.collect()
             assert tag == base_tag + col
+            if base_tag:
+                lat.append(time.perf_counter() - t_sub.pop(col))
             people += n
             col += 1
         return people
@@ -122,6 +128,8 @@ def main():
             "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"COCO 656x368, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU, synthetic weights",
                        "parallelism": f"frame-sharded replicas x{world}"},
+            "latency_ms": {"p50_pipelined": float(np.percentile(lat, 50) * 1e3), "p95_pipelined": float(np.percentile(lat, 95) * 1e3),
+                           "single_frame_device": stage["total"]},
             "stage_ms_last_frame": stage, "roofline": roof, "conv_stack_whole_frame": whole,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -61,7 +61,7 @@ def test_conv_stack_fp32_exact_path(model, W, H, N):
     e.close()
 
 
-@pytest.mark.parametrize("model,W,H,N", [(0, 64, 48, 1), (0, 160, 96, 2)])
+@pytest.mark.parametrize("model,W,H,N", [(0, 64, 48, 1), (0, 160, 96, 2), (1, 96, 64, 2)])
 def test_conv_stack_fp16_path(model, W, H, N):
     """fp16 storage / fp32 accumulate vs the fp32 oracle.  Each layer re-rounds activations to 11
     bits, so the error is a random walk over 52 layers: bound 2e-2 of the blob's max magnitude,
@@ -271,6 +271,37 @@ def test_end_to_end_fp32_vs_oracle_full_chain():
     low = net.forward(x)
     ref_res = orc.imresize(low, W, H, 1.0, 0.3)[0]
     assert np.abs(d["resized"] - ref_res).max() < 1e-3 * max(1.0, np.abs(ref_res).max())
+    e.close()
+
+
+def test_config1_640x480_frame_full_resolution_fp32_vs_full_oracle_chain():
+    """BASELINE config 1 geometry: one 640x480 frame, --resolution 1280x720, --net_resolution 656x368,
+    1 scale.  The WHOLE chain on the oracle (conv stack included, ~5-10 s of CPU) against the fp32
+    engine: maps within 1e-3 of their magnitude; where the peak sets coincide the joints agree to
+    +-1 px / +-1e-3 (north_star tolerance).  Discrete decisions (NMS '>' tests) can flip on 1e-5
+    differences, so peak totals may differ by a few on noise maps."""
+    import caffe_rtpose_amd as r
+    W, H = 656, 368
+    e = _engine(precision=r.PREC_FP32, frames_in_flight=1)
+    net = _oracle_net_from(e)
+    img = r.synth_frame(640, 480, 0, seed=1)
+    x, _, fs = r.preprocess_frame(img, 1280, 720, W, H, 1, 1.0, 0.3)
+    assert fs == 1.5
+    d = e.forward_debug(x)
+    low = net.forward(x)
+    mag = float(np.abs(low).max())
+    assert np.abs(d["lowres"] - low).max() < 1e-3 * mag
+    ref_res = orc.imresize(low, W, H, 1.0, 0.3)[0]
+    assert np.abs(d["resized"] - ref_res).max() < 1e-3 * mag
+    thr = e.get_thresholds()
+    ref_peaks = orc.nms(ref_res, 18, 64, thr["nms_threshold"])
+    tot_ref, tot_eng = ref_peaks[:, 0, 0], d["peaks"][:, 0, 0]
+    assert (np.abs(tot_ref - tot_eng) <= np.maximum(3, 0.02 * tot_ref)).all()
+    same = [p for p in range(18) if tot_ref[p] == tot_eng[p] and tot_ref[p] <= 64]
+    for p in same:
+        n = int(tot_ref[p])
+        assert np.abs(ref_peaks[p, 1:n + 1, :2] - d["peaks"][p, 1:n + 1, :2]).max(initial=0) < 1.0
+        assert np.abs(ref_peaks[p, 1:n + 1, 2] - d["peaks"][p, 1:n + 1, 2]).max(initial=0) < 1e-3 * max(1.0, mag)
     e.close()
 
 
