@@ -48,6 +48,8 @@ SIGNATURES = {
     "rtp_set_scales": (C.c_int, [vp, C.c_float, C.c_float]),
     "rtp_submit": (C.c_int, [vp, fp, C.c_uint64]),
     "rtp_submit_device": (C.c_int, [vp, vp, C.c_uint64]),
+    "rtp_submit_frame": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint64, fp]),
+    "rtp_debug_preprocess": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, fp, C.POINTER(C.c_ubyte), fp]),
     "rtp_collect": (C.c_int, [vp, C.POINTER(C.c_uint64), fp, ip]),
     "rtp_in_flight": (C.c_int, [vp]),
     "rtp_forward_heatmaps": (C.c_int, [vp, fp, fp]),

@@ -31,6 +31,12 @@
 
 using namespace rtp;
 
+void rtp_internal_cubic_tab15(short tab[32][4]);
+int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::vector<int>* si, std::vector<float>* alpha);
+extern "C" double rtp_display_fit_scale(int ow, int oh, int disp_w, int disp_h);
+extern "C" int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h, int num_scales,
+                                    double start_scale, double scale_gap, float* net_input, unsigned char* display_bgr, float* frame_scale);
+
 namespace {
 
 thread_local std::string g_create_error = "";
@@ -85,6 +91,10 @@ struct Ctx {
   int* num_people = nullptr;
   float* host_out = nullptr;  // pinned: [1 int as float slot][joints]
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned char* frame_dev = nullptr;   // raw u8 frame (device) for rtp_submit_frame
+  unsigned char* frame_host = nullptr;  // pinned staging of the raw frame
+  size_t frame_cap = 0;
+  unsigned char* disp_dev = nullptr;    // display-resolution u8 image
   std::vector<hipEvent_t> dom_a, dom_b;  // around every dominant-class conv launch (when timing is on)
   int dom_used = 0;
   uint64_t tag = 0;
@@ -126,6 +136,11 @@ struct rtp_engine {
   bool time_dominant = false;
   double dom_ms_total = 0;
   long dom_launches = 0;
+  // device-side pre-processing (row a1)
+  WarpTab warp_tab;
+  std::vector<AreaScale> area_scales;   // device pointers inside prep_tables
+  unsigned char* prep_tables = nullptr;
+  bool gpu_prep_ok = false;
   unsigned long long* ts_ring = nullptr;  // device: {min start, max end} per timed launch
   int ts_next = 0;
   static const int TS_SLOTS = 32768;
@@ -696,6 +711,9 @@ void free_ctx(Ctx& cx) {
   void* dptrs[] = {cx.arena, cx.input, cx.lowres, cx.resized, cx.peaks, cx.strip_count, cx.strip_list, cx.cand_score, cx.cand_ij,
                    cx.cand_count, cx.conn, cx.conn_score, cx.conn_count, cx.joints, cx.num_people};
   for (void* p : dptrs) if (p) (void)hipFree(p);
+  if (cx.frame_dev) (void)hipFree(cx.frame_dev);
+  if (cx.disp_dev) (void)hipFree(cx.disp_dev);
+  if (cx.frame_host) (void)hipHostFree(cx.frame_host);
   if (cx.host_in) (void)hipHostFree(cx.host_in);
   if (cx.host_out) (void)hipHostFree(cx.host_out);
   for (int i = 0; i < 6; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
@@ -707,6 +725,70 @@ void free_ctx(Ctx& cx) {
 
 int use_device(rtp_engine* e) {
   HIPCHK(e, hipSetDevice(e->cfg.device_id));
+  return RTP_OK;
+}
+
+// INTER_AREA tables of every pyramid level (display resolution -> 16*ceil(net*s/16)) + cubic table
+int build_prep_tables(rtp_engine* e) {
+  rtp_internal_cubic_tab15(e->warp_tab.w);
+  e->gpu_prep_ok = false;
+  struct Host { int tw, th, identity; std::vector<int> xs, xsi, ys, ysi; std::vector<float> xa, ya; };
+  std::vector<Host> hs(e->N);
+  size_t bytes = 0;
+  for (int i = 0; i < e->N; ++i) {
+    const float scale = (float)((double)e->start_scale - i * (double)e->scale_gap);
+    Host& h = hs[i];
+    h.tw = (int)(16 * std::ceil(e->cfg.net_w * scale / 16));
+    h.th = (int)(16 * std::ceil(e->cfg.net_h * scale / 16));
+    h.identity = (h.tw == e->cfg.disp_w && h.th == e->cfg.disp_h) ? 1 : 0;
+    if (h.tw > e->cfg.disp_w || h.th > e->cfg.disp_h) return RTP_OK;  // enlarging level: host path only
+    if (!h.identity) {
+      if (rtp_internal_area_table(e->cfg.disp_w, h.tw, &h.xs, &h.xsi, &h.xa)) return RTP_OK;
+      if (rtp_internal_area_table(e->cfg.disp_h, h.th, &h.ys, &h.ysi, &h.ya)) return RTP_OK;
+    }
+    bytes += 256 * 6 + (h.xs.size() + h.xsi.size() + h.ys.size() + h.ysi.size()) * sizeof(int) + (h.xa.size() + h.ya.size()) * sizeof(float);
+  }
+  std::vector<unsigned char> blob(bytes + 256, 0);
+  if (e->prep_tables) { (void)hipFree(e->prep_tables); e->prep_tables = nullptr; }
+  HIPCHK(e, hipMalloc((void**)&e->prep_tables, blob.size()));
+  size_t off = 0;
+  auto put = [&](const void* p, size_t n) { off = round_up_sz(off, 256); const size_t o = off; if (n) memcpy(blob.data() + o, p, n); off += n; return o; };
+  e->area_scales.assign(e->N, AreaScale{});
+  for (int i = 0; i < e->N; ++i) {
+    Host& h = hs[i];
+    AreaScale& a = e->area_scales[i];
+    a.tw = h.tw; a.th = h.th; a.identity = h.identity;
+    a.xstart = (const int*)(e->prep_tables + put(h.xs.data(), h.xs.size() * sizeof(int)));
+    a.xsi = (const int*)(e->prep_tables + put(h.xsi.data(), h.xsi.size() * sizeof(int)));
+    a.xalpha = (const float*)(e->prep_tables + put(h.xa.data(), h.xa.size() * sizeof(float)));
+    a.ystart = (const int*)(e->prep_tables + put(h.ys.data(), h.ys.size() * sizeof(int)));
+    a.ysi = (const int*)(e->prep_tables + put(h.ysi.data(), h.ysi.size() * sizeof(int)));
+    a.yalpha = (const float*)(e->prep_tables + put(h.ya.data(), h.ya.size() * sizeof(float)));
+  }
+  HIPCHK(e, hipMemcpy(e->prep_tables, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  e->gpu_prep_ok = true;
+  return RTP_OK;
+}
+
+// raw u8 BGR frame (host) -> cx.input on the device
+int enqueue_preprocess(rtp_engine* e, Ctx& cx, const unsigned char* bgr, int w, int h, float* frame_scale) {
+  const size_t fbytes = (size_t)w * h * 3;
+  if (fbytes > cx.frame_cap) {
+    HIPCHK(e, hipStreamSynchronize(cx.stream));
+    if (cx.frame_dev) (void)hipFree(cx.frame_dev);
+    if (cx.frame_host) (void)hipHostFree(cx.frame_host);
+    cx.frame_dev = nullptr; cx.frame_host = nullptr; cx.frame_cap = 0;
+    HIPCHK(e, hipMalloc((void**)&cx.frame_dev, fbytes));
+    HIPCHK(e, hipHostMalloc((void**)&cx.frame_host, fbytes, hipHostMallocDefault));
+    cx.frame_cap = fbytes;
+  }
+  if (!cx.disp_dev) HIPCHK(e, hipMalloc((void**)&cx.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3));
+  const double s = rtp_display_fit_scale(w, h, e->cfg.disp_w, e->cfg.disp_h);
+  if (frame_scale) *frame_scale = (float)s;
+  memcpy(cx.frame_host, bgr, fbytes);
+  HIPCHK(e, hipMemcpyAsync(cx.frame_dev, cx.frame_host, fbytes, hipMemcpyHostToDevice, cx.stream));
+  HIPCHK(e, launch_warp(cx.frame_dev, w, h, 1.0 / s, e->warp_tab, cx.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
+  HIPCHK(e, launch_area_pad(cx.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, cx.input, e->cfg.net_w, e->cfg.net_h, cx.stream));
   return RTP_OK;
 }
 
@@ -745,6 +827,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   if (e->dweights) (void)hipFree(e->dweights);
   if (e->dchmap) (void)hipFree(e->dchmap);
   if (e->ts_ring) (void)hipFree(e->ts_ring);
+  if (e->prep_tables) (void)hipFree(e->prep_tables);
   delete e;
 }
 
@@ -834,6 +917,7 @@ int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
   e->ctx.resize(cfg->frames_in_flight);
   for (auto& c : e->ctx)
     if ((rc = alloc_ctx(e, c))) return bail(rc);
+  if ((rc = build_prep_tables(e))) return bail(rc);
   // dry run, as warmup() does (rtpose.cpp:233)
   {
     Ctx& cx = e->ctx[0];
@@ -881,6 +965,12 @@ int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap) {
   if (!e) return RTP_EINVAL;
   e->start_scale = start_scale;
   e->scale_gap = scale_gap;
+  if (!e->ctx.empty()) {
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    HIPCHK(e, hipDeviceSynchronize());
+    if ((rc = build_prep_tables(e))) return rc;
+  }
   return RTP_OK;
 }
 
@@ -918,6 +1008,46 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   cx.tag = tag;
   cx.busy = true;
   e->fifo.push_back(ci);
+  return RTP_OK;
+}
+
+// Replaces the producer's per-frame OpenCV work + H2D (rtpose.cpp:322-368, 1131-1133): raw u8 BGR frame
+// in, pre-processing on the device (preproc.hip), then the same frame path as rtp_submit.
+int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint64_t tag, float* frame_scale) {
+  if (!e || !bgr || w < 1 || h < 1) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  const int ci = pick_ctx(e);
+  if (ci < 0) return fail(e, RTP_EAGAIN, "all %zu frame contexts are busy", e->ctx.size());
+  Ctx& cx = e->ctx[ci];
+  if (e->gpu_prep_ok) {
+    if ((rc = enqueue_preprocess(e, cx, bgr, w, h, frame_scale))) return rc;
+  } else {  // a pyramid level would have to be enlarged: host restatement (linear fallback) + H2D
+    const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
+    rc = rtp_preprocess_frame(bgr, w, h, e->cfg.disp_w, e->cfg.disp_h, e->cfg.net_w, e->cfg.net_h, e->N, e->start_scale, e->scale_gap,
+                              cx.host_in, nullptr, frame_scale);
+    if (rc) return fail(e, rc, "pre-processing failed (a scale does not fit the net resolution?)");
+    HIPCHK(e, hipMemcpyAsync(cx.input, cx.host_in, bytes, hipMemcpyHostToDevice, cx.stream));
+  }
+  if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
+  cx.tag = tag;
+  cx.busy = true;
+  e->fifo.push_back(ci);
+  return RTP_OK;
+}
+
+static int need_idle(rtp_engine* e);
+// Parity tap: the device pre-processing alone (net input and display image back on the host).
+int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, float* net_input, unsigned char* display_bgr, float* frame_scale) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!bgr || w < 1 || h < 1) return RTP_EINVAL;
+  if (!e->gpu_prep_ok) return fail(e, RTP_EINVAL, "device pre-processing unavailable for this configuration (a level would be enlarged)");
+  Ctx& cx = e->ctx[0];
+  if ((rc = enqueue_preprocess(e, cx, bgr, w, h, frame_scale))) return rc;
+  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  if (net_input) HIPCHK(e, hipMemcpy(net_input, cx.input, (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
+  if (display_bgr) HIPCHK(e, hipMemcpy(display_bgr, cx.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3, hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 

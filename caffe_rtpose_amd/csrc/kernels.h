@@ -91,6 +91,20 @@ hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* ch
                          hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
+// Pre-processing on the device (row a1): see preproc.hip
+// ---------------------------------------------------------------------------------------
+struct WarpTab { short w[32][4]; };  // 15-bit fixed-point cubic weights per 1/32-pixel phase
+struct AreaScale {                    // cv::resize(INTER_AREA) tables of one pyramid level (device pointers)
+  int tw, th, identity;
+  const int* xstart; const int* xsi; const float* xalpha;   // entries of dst column x: [xstart[x], xstart[x+1])
+  const int* ystart; const int* ysi; const float* yalpha;
+};
+hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const WarpTab& tab, unsigned char* dst, int dw, int dh,
+                       hipStream_t stream);
+hipError_t launch_area_pad(const unsigned char* disp, int dw, int dh, const AreaScale* scales, int nscales, float* out, int net_w, int net_h,
+                           hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
 // Post-processing (bit-exact restatements of the reference's CUDA kernels / host loop).
 // ---------------------------------------------------------------------------------------
 struct ResizeParams {

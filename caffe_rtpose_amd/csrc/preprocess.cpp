@@ -96,17 +96,22 @@ void cubic_coeffs(float x, float* c) {
   c[3] = 1.f - c[0] - c[1] - c[2];
 }
 
-void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale, unsigned char* dst, int dw, int dh) {
-  const int INTER_BITS = 5, INTER_TAB = 1 << INTER_BITS, AB_BITS = 10, AB_SCALE = 1 << AB_BITS, COEF_BITS = 15;
-  // 1-D cubic tables in 15-bit fixed point (initInterTab2D: weights sum to 1 << 15, the remainder goes to the largest)
-  short tab[32][4];
-  for (int i = 0; i < INTER_TAB; ++i) {
+// 1-D cubic tables in 15-bit fixed point (initInterTab2D: weights sum to 1 << 15, the remainder goes to the largest)
+void cubic_tab15(short tab[32][4]) {
+  const int COEF_BITS = 15;
+  for (int i = 0; i < 32; ++i) {
     float c[4];
-    cubic_coeffs((float)i / INTER_TAB, c);
+    cubic_coeffs((float)i / 32, c);
     int isum = 0, kmax = 0;
     for (int k = 0; k < 4; ++k) { tab[i][k] = (short)cv_round(c[k] * (1 << COEF_BITS)); isum += tab[i][k]; if (c[k] > c[kmax]) kmax = k; }
     tab[i][kmax] = (short)(tab[i][kmax] + ((1 << COEF_BITS) - isum));
   }
+}
+
+void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale, unsigned char* dst, int dw, int dh) {
+  const int INTER_BITS = 5, INTER_TAB = 1 << INTER_BITS, AB_BITS = 10, AB_SCALE = 1 << AB_BITS, COEF_BITS = 15;
+  short tab[32][4];
+  cubic_tab15(tab);
   const double inv = 1.0 / scale;  // warpAffine inverts M unless WARP_INVERSE_MAP
   const int round_delta = AB_SCALE / INTER_TAB / 2;
   for (int y = 0; y < dh; ++y) {
@@ -137,6 +142,25 @@ void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale,
 }
 
 }  // namespace
+
+// shared with the device path (engine.cpp uploads exactly these tables)
+void rtp_internal_cubic_tab15(short tab[32][4]) { cubic_tab15(tab); }
+int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::vector<int>* si, std::vector<float>* alpha) {
+  if (dsize > ssize) return -1;  // enlarging: the host path falls back to linear interpolation
+  std::vector<AreaTab> tab;
+  area_tab(ssize, dsize, (double)ssize / dsize, tab);
+  start->assign(dsize + 1, 0);
+  si->clear();
+  alpha->clear();
+  int cur = 0;
+  for (size_t i = 0; i < tab.size(); ++i) {
+    while (cur <= tab[i].di) (*start)[cur++] = (int)i;
+    si->push_back(tab[i].si);
+    alpha->push_back(tab[i].alpha);
+  }
+  while (cur <= dsize) (*start)[cur++] = (int)tab.size();
+  return 0;
+}
 
 extern "C" {
 

@@ -41,6 +41,7 @@ double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::
 
 // ---- flags (names and defaults: rtpose.cpp:50-72) --------------------------------------------
 struct Flags {
+  bool host_preprocess = false;
   bool fullscreen = false, no_frame_drops = false, no_display = false, no_text = false, logtostderr = false;
   int part_to_show = 0, camera = 0, start_frame = 0, start_device = 0, num_gpu = 1, num_scales = 1;
   std::string write_frames, write_json, video, image_dir;
@@ -60,7 +61,7 @@ int parse_flags(int argc, char** argv, Flags& F) {
   std::map<std::string, int*> iflags = {{"part_to_show", &F.part_to_show}, {"camera", &F.camera}, {"start_frame", &F.start_frame},
       {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}};
   std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}};
-  std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"no_display", &F.no_display},
+  std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"host_preprocess", &F.host_preprocess}, {"no_display", &F.no_display},
       {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -99,7 +100,7 @@ void usage() {
          "  --caffeproto FILE --caffemodel FILE   | --model coco|mpi (built-in graph, synthetic weights)\n"
          "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
          "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
-         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K]\n");
+         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K --host_preprocess]\n");
 }
 
 // ---- queues (caffe::BlockingQueue, util/blocking_queue.cpp:26-61) -----------------------------
@@ -122,7 +123,9 @@ template <typename T> class BlockingQueue {
 
 // include/caffe/cpm/frame.h:6-34
 struct Frame {
-  std::vector<float> data;  // net input
+  std::vector<float> data;         // net input (only with --host_preprocess)
+  std::vector<unsigned char> image;  // decoded u8 BGR frame (default: pre-processing runs on the GPU)
+  int img_w = 0, img_h = 0;
   double commit_time = 0, preprocessed_time = 0, gpu_fetched_time = 0, gpu_computed_time = 0, buffer_start_time = 0, buffer_end_time = 0;
   int index = 0, numPeople = 0, video_frame_number = 0;
   float scale = 1.f;
@@ -176,10 +179,16 @@ void producer() {
       fr.stem = path.substr(sl == std::string::npos ? 0 : sl + 1, dot - (sl == std::string::npos ? 0 : sl + 1));
     }
     fr.commit_time = wall();
-    fr.data.resize((size_t)F.num_scales * 3 * NET_H * NET_W);
-    if (rtp_preprocess_frame(img.data(), w, h, DISP_W, DISP_H, NET_W, NET_H, F.num_scales, F.start_scale, F.scale_gap, fr.data.data(), nullptr, &fr.scale) != RTP_OK) {
-      fprintf(stderr, "preprocess failed for frame %d\n", fi);
-      continue;
+    if (F.host_preprocess) {
+      fr.data.resize((size_t)F.num_scales * 3 * NET_H * NET_W);
+      if (rtp_preprocess_frame(img.data(), w, h, DISP_W, DISP_H, NET_W, NET_H, F.num_scales, F.start_scale, F.scale_gap, fr.data.data(), nullptr, &fr.scale) != RTP_OK) {
+        fprintf(stderr, "preprocess failed for frame %d\n", fi);
+        continue;
+      }
+    } else {
+      fr.image = img;
+      fr.img_w = w;
+      fr.img_h = h;
     }
     fr.index = global_counter++;
     fr.video_frame_number = fi;
@@ -241,7 +250,11 @@ void worker(int device, int* status) {
         G.dropped++;
         continue;
       }
-      if (rtp_submit(e, fr.data.data(), (uint64_t)fr.index) != RTP_OK) { fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(e)); *status = 1; break; }
+      const int src = F.host_preprocess ? rtp_submit(e, fr.data.data(), (uint64_t)fr.index)
+                                        : rtp_submit_frame(e, fr.image.data(), fr.img_w, fr.img_h, (uint64_t)fr.index, &fr.scale);
+      fr.image.clear();
+      fr.image.shrink_to_fit();
+      if (src != RTP_OK) { fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(e)); *status = 1; break; }
       inflight.push_back(std::move(fr));
       if ((int)inflight.size() < F.frames_in_flight) continue;
     }

@@ -229,6 +229,21 @@ class Engine:
     def submit_device(self, dptr, tag=0):
         self._chk(lib.rtp_submit_device(self.h, C.c_void_p(dptr), tag))
 
+    def submit_frame(self, img_u8, tag=0):
+        img = np.ascontiguousarray(img_u8, np.uint8)
+        fs = C.c_float()
+        self._chk(lib.rtp_submit_frame(self.h, img.ctypes.data_as(C.POINTER(C.c_ubyte)), img.shape[1], img.shape[0], tag, C.byref(fs)))
+        return fs.value
+
+    def debug_preprocess(self, img_u8):
+        img = np.ascontiguousarray(img_u8, np.uint8)
+        x = np.empty((self.N, 3, self.net_h, self.net_w), np.float32)
+        disp = np.empty((self.cfg.c.disp_h, self.cfg.c.disp_w, 3), np.uint8)
+        fs = C.c_float()
+        self._chk(lib.rtp_debug_preprocess(self.h, img.ctypes.data_as(C.POINTER(C.c_ubyte)), img.shape[1], img.shape[0], _f(x),
+                                           disp.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(fs)))
+        return x, disp, fs.value
+
     def collect(self):
         tag = C.c_uint64()
         n = C.c_int()

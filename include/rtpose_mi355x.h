@@ -99,6 +99,15 @@ int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap);
 int rtp_submit(rtp_engine* e, const float* nchw_input_host, uint64_t tag);
 int rtp_submit_device(rtp_engine* e, const float* nchw_input_device, uint64_t tag);
 
+/* Same frame path, but from the DECODED frame: u8 BGR HWC (any size) -> display-fit cubic warp ->
+ * INTER_AREA scale pyramid -> u8/256-0.5 -> centre pad, all on the device (what the producer thread
+ * does with OpenCV in rtpose.cpp:322-368), bit-identical to rtp_preprocess_frame.  *frame_scale
+ * receives Frame::scale (for rtp_format_json). */
+int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr_host, int w, int h, uint64_t tag, float* frame_scale);
+/* Parity tap for the device pre-processing alone. */
+int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr_host, int w, int h, float* net_input_host,
+                         unsigned char* display_bgr_host, float* frame_scale);
+
 /* Blocks until the OLDEST submitted frame is finished; returns its tag, the number of people
  * (<= RTP_MAX_PEOPLE) and joints[num_people][num_parts][3] = (x, y, score) in display
  * coordinates — the array connectLimbs*() fills (rtpose.cpp:1051-1073).  joints must hold

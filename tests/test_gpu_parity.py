@@ -321,3 +321,69 @@ def test_weights_roundtrip_caffemodel_and_prototxt(tmp_path):
     b = e2.forward_heatmaps(x)
     assert np.array_equal(a, b)
     e2.close()
+
+
+# ------------------------------------------------------------------------------------------
+# row a1 on the device: u8 frame -> net input (bit-exact with the host restatement)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fw,fh,dw,dh,W,H,N,start,gap", [
+    (1280, 720, 1280, 720, 656, 368, 1, 1.0, 0.3),     # reference defaults (rtpose.cpp:50-72)
+    (1920, 1080, 1280, 720, 656, 368, 3, 1.0, 0.15),   # down-warp + 3-scale pyramid
+    (640, 480, 1280, 720, 656, 368, 2, 1.0, 0.25),     # up-warp with a zero border on the right
+    (333, 517, 640, 480, 320, 240, 4, 1.0, 0.2),       # odd sizes, portrait, 4 scales
+    (640, 480, 656, 368, 656, 368, 1, 1.0, 0.3),       # display == net: identity level (memcpy branch)
+])
+def test_device_preprocess_bit_exact(fw, fh, dw, dh, W, H, N, start, gap):
+    import caffe_rtpose_amd as r
+    e = _engine(net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, disp_w=dw, disp_h=dh, frames_in_flight=1)
+    for idx in (0, 3):
+        img = r.synth_frame(fw, fh, idx, seed=11)
+        if idx == 3:  # noise: every rounding boundary gets exercised
+            img = np.random.default_rng(5).integers(0, 256, img.shape, dtype=np.uint8)
+        want_x, want_disp, want_fs = r.preprocess_frame(img, dw, dh, W, H, N, start, gap)
+        x, disp, fs = e.debug_preprocess(img)
+        assert fs == want_fs
+        assert np.array_equal(disp, want_disp)
+        assert np.array_equal(x, want_x)
+    e.close()
+
+
+def test_submit_frame_equals_host_preprocess_plus_submit():
+    import caffe_rtpose_amd as r
+    e = _engine(net_w=320, net_h=176, num_scales=2, scale_gap=0.25, disp_w=640, disp_h=360, frames_in_flight=3)
+    imgs = [r.synth_frame(*wh, i, seed=3) for i, wh in enumerate([(800, 600), (640, 360), (1280, 720), (320, 200), (801, 603)])]
+    ref = []
+    for im in imgs:
+        x, _, fs = r.preprocess_frame(im, 640, 360, 320, 176, 2, 1.0, 0.25)
+        e.submit(x, tag=1)
+        ref.append((e.collect(), fs))
+    got = []
+    pending = []
+    for i, im in enumerate(imgs):  # keep 3 in flight, frames of different sizes reuse the staging buffers
+        pending.append(e.submit_frame(im, tag=100 + i))
+        if len(pending) == 3:
+            got.append((e.collect(), pending.pop(0)))
+    while pending:
+        got.append((e.collect(), pending.pop(0)))
+    for i, ((tag, n, joints), fs) in enumerate(got):
+        (_, rn, rj), rfs = ref[i]
+        assert tag == 100 + i and n == rn and fs == rfs
+        assert np.array_equal(joints, rj)
+    e.close()
+
+
+def test_submit_frame_enlarging_level_falls_back_to_host_restatement():
+    """display smaller than the net input: the INTER_AREA level would enlarge; the engine then
+    runs the host restatement (linear branch) — still the same numbers as rtp_preprocess_frame."""
+    import caffe_rtpose_amd as r
+    e = _engine(net_w=160, net_h=96, num_scales=1, disp_w=120, disp_h=80, frames_in_flight=1)
+    img = r.synth_frame(320, 240, 1, seed=9)
+    x, _, fs = r.preprocess_frame(img, 120, 80, 160, 96, 1, 1.0, 0.3)
+    e.submit(x, tag=5)
+    want = e.collect()
+    fs2 = e.submit_frame(img, tag=5)
+    got = e.collect()
+    assert fs2 == fs and got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
+    with pytest.raises(r.RtpError):
+        e.debug_preprocess(img)
+    e.close()
