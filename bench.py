@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--scale_gap", type=float, default=0.3)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--in_flight", type=int, default=8)
+    ap.add_argument("--batch_frames", type=int, default=1, help="frames whose conv stacks share one launch sequence")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 
@@ -68,7 +69,7 @@ def main():
     seed = 1
     prec = r.PREC_FP16 if args.precision == "fp16" else r.PREC_FP32
     eng = r.Engine(r.Config(device_id=local, model=r.MODEL_COCO_18, net_w=656, net_h=368, num_scales=args.num_scales,
-                            scale_gap=args.scale_gap, precision=prec, frames_in_flight=args.in_flight, synthetic_seed=seed))
+                            scale_gap=args.scale_gap, precision=prec, frames_in_flight=args.in_flight, batch_frames=args.batch_frames, synthetic_seed=seed))
     # synthetic frames, resident in HBM before the timed region (u8/256-0.5 like process_and_pad_image)
     nframes = 8
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -126,7 +127,7 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": f"COCO 656x368, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU, synthetic weights",
+            "config": {"workload": f"COCO 656x368, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU in batches of {args.batch_frames}, synthetic weights",
                        "parallelism": f"frame-sharded replicas x{world}"},
             "latency_ms": {"p50_pipelined": float(np.percentile(lat, 50) * 1e3), "p95_pipelined": float(np.percentile(lat, 95) * 1e3),
                            "single_frame_device": stage["total"]},

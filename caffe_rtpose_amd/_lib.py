@@ -30,6 +30,7 @@ class rtp_config(C.Structure):
         ("disp_h", C.c_int),
         ("precision", C.c_int),
         ("frames_in_flight", C.c_int),
+        ("batch_frames", C.c_int),
     ]
 
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "rtp_submit_device": (C.c_int, [vp, vp, C.c_uint64]),
     "rtp_submit_frame": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint64, fp]),
     "rtp_debug_preprocess": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, fp, C.POINTER(C.c_ubyte), fp]),
+    "rtp_flush": (C.c_int, [vp]),
     "rtp_collect": (C.c_int, [vp, C.POINTER(C.c_uint64), fp, ip]),
     "rtp_in_flight": (C.c_int, [vp]),
     "rtp_forward_heatmaps": (C.c_int, [vp, fp, fp]),

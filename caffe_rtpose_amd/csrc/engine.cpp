@@ -71,12 +71,10 @@ struct Step {
 
 struct PoolOp { int in_tensor, out_tensor, C; };
 
-struct Ctx {
-  hipStream_t stream = nullptr;
-  unsigned char* arena = nullptr;
-  float* input = nullptr;     // device NCHW fp32
-  float* host_in = nullptr;   // pinned staging
-  float* lowres = nullptr;
+// One frame's post-processing state (a batch context carries batch_frames of them)
+struct Slot {
+  hipStream_t stream = nullptr;  // resize -> nms -> connect -> D2H of this frame (slot 0 shares the context's stream)
+  bool own_stream = false;
   float* resized = nullptr;
   float* peaks = nullptr;
   int* strip_count = nullptr;
@@ -90,15 +88,28 @@ struct Ctx {
   float* joints = nullptr;
   int* num_people = nullptr;
   float* host_out = nullptr;  // pinned: [1 int as float slot][joints]
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // post start, resize, nms, connect, results on host
   unsigned char* frame_dev = nullptr;   // raw u8 frame (device) for rtp_submit_frame
   unsigned char* frame_host = nullptr;  // pinned staging of the raw frame
   size_t frame_cap = 0;
   unsigned char* disp_dev = nullptr;    // display-resolution u8 image
-  std::vector<hipEvent_t> dom_a, dom_b;  // around every dominant-class conv launch (when timing is on)
-  int dom_used = 0;
   uint64_t tag = 0;
   bool busy = false;
+};
+
+// One batch in flight: the conv stack runs once over filled*num_scales images
+struct Ctx {
+  hipStream_t stream = nullptr;
+  unsigned char* arena = nullptr;
+  float* input = nullptr;     // device NCHW fp32, batch_frames * num_scales images
+  float* host_in = nullptr;   // pinned staging
+  float* lowres = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};  // around the conv stack
+  std::vector<Slot> slot;
+  int filled = 0;        // frames staged in the open batch
+  bool launched = false;
+  std::vector<hipEvent_t> dom_a, dom_b;  // around every dominant-class conv launch (when timing is on)
+  int dom_used = 0;
 };
 
 }  // namespace
@@ -113,7 +124,10 @@ struct rtp_engine {
   float nms_threshold = 0.05f, inter_threshold = 0.05f, min_subset_score = 0.4f;
   int inter_min_above = 9, min_subset_cnt = 3;
   float start_scale = 1.f, scale_gap = 0.3f;
-  int N = 1;
+  int N = 1;    // images per frame (num_scales)
+  int B = 1;    // frames per batch (cfg.batch_frames)
+  int NI = 1;   // images per conv launch at a full batch = N * B
+  int open_ctx = -1;  // context whose batch is being filled
   Geom geom[8];
   int nlevels = 0;
   std::vector<Tensor> tensors;
@@ -258,7 +272,7 @@ int build_plan(rtp_engine* e) {
   else if (e->num_parts == 15) e->model = RTP_MODEL_MPI_15;
   else return fail(e, RTP_EINVAL, "Unknown number of parts (%d)! Couldn't set model", e->num_parts);  // rtpose.cpp:227
   e->num_limbs = e->model == 0 ? 19 : 14;
-  if (e->max_peaks < 1 || e->max_peaks > 256) return fail(e, RTP_EINVAL, "max_peaks %d out of range [1,256]", e->max_peaks);
+  if (e->max_peaks < 1 || e->max_peaks > 127) return fail(e, RTP_EINVAL, "max_peaks %d out of range [1,127]", e->max_peaks);
   e->heat_channels = e->blob_dims[e->lowres_blob].first;
   if (e->blob_dims[e->lowres_blob].second != 3) return fail(e, RTP_EINVAL, "resize input must be at 1/8 resolution");
   {
@@ -272,7 +286,7 @@ int build_plan(rtp_engine* e) {
     return fail(e, RTP_EINVAL, "net_resolution %dx%d must be positive multiples of 16", e->cfg.net_w, e->cfg.net_h);
   for (int l = 0; l < e->nlevels; ++l) {
     Geom g;
-    g.N = e->N; g.H = e->cfg.net_h >> l; g.W = e->cfg.net_w >> l; g.halo = level_halo[l];
+    g.N = e->NI; g.H = e->cfg.net_h >> l; g.W = e->cfg.net_w >> l; g.halo = level_halo[l];
     g.Hp = g.H + 2 * g.halo; g.Wp = g.W + 2 * g.halo; g.img_pix = (long)g.Hp * g.Wp;
     e->geom[l] = g;
   }
@@ -408,7 +422,7 @@ int build_plan(rtp_engine* e) {
     bool chosen = false;
     for (int cf : cands) {
       const ConvCfgInfo ci = conv_cfg_info(cf);
-      const long wg = ((M + ci.BM - 1) / ci.BM) * e->N * (round_up(maxcout, ci.BN) / ci.BN) * nprob;
+      const long wg = ((M + ci.BM - 1) / ci.BM) * e->NI * (round_up(maxcout, ci.BN) / ci.BN) * nprob;
       const double bytes = (double)wg * (ci.BN + (double)(ci.BM + A.k_eff - 1) / A.k_eff);
       if (wg >= 224) {
         if (!chosen || bytes < best_bytes) { best = cf; best_bytes = bytes; chosen = true; }
@@ -450,7 +464,7 @@ int build_plan(rtp_engine* e) {
     off += GUARD_PIX * pix_bytes;
     off = round_up_sz(off, 256);
     t.offset = off;
-    off += (size_t)e->N * g.img_pix * pix_bytes + GUARD_PIX * pix_bytes;
+    off += (size_t)e->NI * g.img_pix * pix_bytes + GUARD_PIX * pix_bytes;
   }
   e->arena_bytes = round_up_sz(off, 256) + (4u << 20);  // tail pad: the ring kernel's dummy prefetches read past the last strip
   // weight arena
@@ -475,9 +489,9 @@ int build_plan(rtp_engine* e) {
   e->nstrips = (e->cfg.net_h + e->strip_rows - 1) / e->strip_rows;
   e->max_rows = e->num_limbs * e->max_peaks;
   {
-    const size_t lds2 = (size_t)e->max_rows * (sizeof(double) + sizeof(int) + sizeof(int) * e->num_parts);
-    const size_t lds1 = 2 * (size_t)e->max_peaks * e->max_peaks * 8;
-    if (lds2 > 150 * 1024 || lds1 > 150 * 1024) return fail(e, RTP_EINVAL, "max_peaks %d needs more LDS than a CU has", e->max_peaks);
+    // connect kernels: sort keys hold 7-bit peak ordinals; the subset table is int16 in LDS
+    const size_t lds2 = (size_t)e->max_rows * (sizeof(double) + sizeof(short) + sizeof(short) * e->num_parts);
+    if (e->max_peaks > 127 || lds2 > 150 * 1024) return fail(e, RTP_EINVAL, "max_peaks %d out of range [1,127]", e->max_peaks);
   }
   return RTP_OK;
 }
@@ -560,7 +574,7 @@ void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProbl
   pr->Cout = c.cout;
 }
 
-int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, unsigned long long* tstamp = nullptr) {
+int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned long long* tstamp = nullptr) {
   const ConvOp& A = e->convs[s.a];
   const Geom& g = e->geom[A.level];
   ConvParams P;
@@ -575,7 +589,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, unsigned long long* 
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
   P.relu = A.relu ? 1 : 0;
   P.tstamp = tstamp;
-  P.nimg = e->N;
+  P.nimg = nimg;
   {
     static const char* rot = getenv("RTP_CONV_ROTATE");
     P.rotate = (rot && rot[0] == '0') ? 0 : 1;
@@ -586,8 +600,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, unsigned long long* 
     static const char* ab = getenv("RTP_RING_ABLATE");
     P.ablate = ab ? atoi(ab) : 0;
   }
-  if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
-  else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, e->N, cx.stream));
+  if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
+  else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   return RTP_OK;
 }
 
@@ -601,75 +615,116 @@ bool is_dominant_class(const rtp_engine* e, const Step& s) {
   return a.k == d.k && a.cin == d.cin && a.cout == d.cout && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
 }
 
-int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev) {
+int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg) {
   const std::vector<PoolOp>& pools = e->pools;
   cx.dom_used = 0;
+  auto geom_n = [&](int level) { Geom g = e->geom[level]; g.N = nimg; return g; };
   for (auto& s : e->steps) {
     if (s.type == 0) {
       const Tensor& t = e->tensors[0];
-      HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, e->geom[0], t.Cp, cx.stream));
+      HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, geom_n(0), t.Cp, cx.stream));
     } else if (s.type == 1) {
       const bool timed = e->time_dominant && e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS && is_dominant_class(e, s);
-      const int rc = launch_conv_step(e, cx, s, timed ? e->ts_ring + 2 * (size_t)e->ts_next : nullptr);
+      const int rc = launch_conv_step(e, cx, s, nimg, timed ? e->ts_ring + 2 * (size_t)e->ts_next : nullptr);
       if (rc) return rc;
       if (timed) e->ts_next++;
     } else {
       const PoolOp& p = pools[s.a];
       const Tensor& ti = e->tensors[p.in_tensor];
       const Tensor& to = e->tensors[p.out_tensor];
-      HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, e->geom[ti.level], ti.Cp, cx.arena + to.offset, e->geom[to.level], to.Cp,
+      HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.Cp, cx.arena + to.offset, geom_n(to.level), to.Cp,
                                round_up(p.C, 16 / e->elem), cx.stream));
     }
   }
   return RTP_OK;
 }
 
-int run_resize(rtp_engine* e, Ctx& cx) {
+int run_resize(rtp_engine* e, Ctx& cx, int sj = 0) {
+  Slot& sl = cx.slot[sj];
   ResizeParams rp;
-  rp.src = cx.lowres; rp.dst = cx.resized; rp.num = e->N; rp.C = e->heat_channels;
+  rp.src = cx.lowres + (size_t)sj * e->N * e->heat_channels * e->low_h * e->low_w;
+  rp.dst = sl.resized; rp.num = e->N; rp.C = e->heat_channels;
   rp.h = e->low_h; rp.w = e->low_w; rp.tw = e->cfg.net_w; rp.th = e->cfg.net_h;
   rp.start_scale = e->start_scale; rp.scale_gap = e->scale_gap;
-  HIPCHK(e, launch_resize(rp, cx.stream));
+  HIPCHK(e, launch_resize(rp, sl.stream));
   return RTP_OK;
 }
-int run_nms(rtp_engine* e, Ctx& cx) {
+int run_nms(rtp_engine* e, Ctx& cx, int sj = 0) {
+  Slot& sl = cx.slot[sj];
   NmsParams np;
-  np.src = cx.resized; np.peaks = cx.peaks; np.strip_count = cx.strip_count; np.strip_list = cx.strip_list;
+  np.src = sl.resized; np.peaks = sl.peaks; np.strip_count = sl.strip_count; np.strip_list = sl.strip_list;
   np.src_planes = e->heat_channels; np.H = e->cfg.net_h; np.W = e->cfg.net_w; np.num_parts = e->num_parts;
   np.max_peaks = e->max_peaks; np.nstrips = e->nstrips; np.strip_rows = e->strip_rows; np.threshold = e->nms_threshold;
-  HIPCHK(e, launch_nms(np, cx.stream));
+  HIPCHK(e, launch_nms(np, sl.stream));
   return RTP_OK;
 }
-int run_connect(rtp_engine* e, Ctx& cx) {
+int run_connect(rtp_engine* e, Ctx& cx, int sj = 0) {
+  Slot& sl = cx.slot[sj];
   ConnectParams cp;
   memset(&cp, 0, sizeof cp);
-  cp.heat = cx.resized; cp.peaks = cx.peaks; cp.joints = cx.joints; cp.num_people = cx.num_people;
-  cp.cand_score = cx.cand_score; cp.cand_ij = cx.cand_ij; cp.cand_count = cx.cand_count;
-  cp.conn = cx.conn; cp.conn_score = cx.conn_score; cp.conn_count = cx.conn_count;
+  cp.heat = sl.resized; cp.peaks = sl.peaks; cp.joints = sl.joints; cp.num_people = sl.num_people;
+  cp.cand_score = sl.cand_score; cp.cand_ij = sl.cand_ij; cp.cand_count = sl.cand_count;
+  cp.conn = sl.conn; cp.conn_score = sl.conn_score; cp.conn_count = sl.conn_count;
   cp.max_rows = e->max_rows; cp.model = e->model; cp.num_parts = e->num_parts; cp.num_limbs = e->num_limbs;
   cp.max_peaks = e->max_peaks; cp.net_w = e->cfg.net_w; cp.net_h = e->cfg.net_h; cp.disp_w = e->cfg.disp_w; cp.disp_h = e->cfg.disp_h;
   cp.inter_threshold = e->inter_threshold; cp.inter_min_above = e->inter_min_above; cp.min_subset_cnt = e->min_subset_cnt;
   cp.min_subset_score = e->min_subset_score; cp.max_people = RTP_MAX_PEOPLE;
-  HIPCHK(e, launch_connect(cp, cx.stream));
+  HIPCHK(e, launch_connect(cp, sl.stream));
   return RTP_OK;
 }
 
-// whole frame on one context: conv stack -> resize -> nms -> connect -> D2H of joints
-int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev) {
+// one batch on one context: conv stack over nframes*num_scales images, then per frame (on the
+// frame slot's stream) resize -> nms -> connect -> D2H of the joints
+int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev) {
   int rc;
   HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
-  if ((rc = run_frame_stack(e, cx, input_dev))) return rc;
+  if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N))) return rc;
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
-  if ((rc = run_resize(e, cx))) return rc;
-  HIPCHK(e, hipEventRecord(cx.ev[2], cx.stream));
-  if ((rc = run_nms(e, cx))) return rc;
-  HIPCHK(e, hipEventRecord(cx.ev[3], cx.stream));
-  if ((rc = run_connect(e, cx))) return rc;
-  HIPCHK(e, hipEventRecord(cx.ev[4], cx.stream));
   const size_t jbytes = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3 * sizeof(float);
-  HIPCHK(e, hipMemcpyAsync(cx.host_out + 4, cx.joints, jbytes, hipMemcpyDeviceToHost, cx.stream));
-  HIPCHK(e, hipMemcpyAsync(cx.host_out, cx.num_people, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
-  HIPCHK(e, hipEventRecord(cx.ev[5], cx.stream));
+  for (int j = 0; j < nframes; ++j) {
+    Slot& sl = cx.slot[j];
+    if (sl.stream != cx.stream) HIPCHK(e, hipStreamWaitEvent(sl.stream, cx.ev[1], 0));
+    static const char* diag = getenv("RTP_DIAG_SKIP_POST");  // diagnosis only: 1 = no connect, 2 = no post-processing at all
+    const int skip = diag ? atoi(diag) : 0;
+    HIPCHK(e, hipEventRecord(sl.ev[0], sl.stream));
+    if (skip < 2 && (rc = run_resize(e, cx, j))) return rc;
+    HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
+    if (skip < 2 && (rc = run_nms(e, cx, j))) return rc;
+    HIPCHK(e, hipEventRecord(sl.ev[2], sl.stream));
+    if (skip < 1 && (rc = run_connect(e, cx, j))) return rc;
+    HIPCHK(e, hipEventRecord(sl.ev[3], sl.stream));
+    HIPCHK(e, hipMemcpyAsync(sl.host_out + 4, sl.joints, jbytes, hipMemcpyDeviceToHost, sl.stream));
+    HIPCHK(e, hipMemcpyAsync(sl.host_out, sl.num_people, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
+    HIPCHK(e, hipEventRecord(sl.ev[4], sl.stream));
+  }
+  cx.launched = true;
+  return RTP_OK;
+}
+int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev) { return launch_batch(e, cx, 1, input_dev); }
+
+int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
+  if (share_stream) sl.stream = cx.stream;
+  else { HIPCHK(e, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)); sl.own_stream = true; }
+  const size_t res_floats = (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w;
+  HIPCHK(e, hipMalloc((void**)&sl.resized, res_floats * sizeof(float)));
+  const size_t peak_floats = (size_t)e->num_parts * (e->max_peaks + 1) * 3;
+  HIPCHK(e, hipMalloc((void**)&sl.peaks, peak_floats * sizeof(float)));
+  HIPCHK(e, hipMemset(sl.peaks, 0, peak_floats * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&sl.strip_count, (size_t)e->num_parts * e->nstrips * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&sl.strip_list, (size_t)e->num_parts * e->nstrips * e->max_peaks * sizeof(int)));
+  const size_t pairs = (size_t)e->num_limbs * e->max_peaks * e->max_peaks;
+  HIPCHK(e, hipMalloc((void**)&sl.cand_score, pairs * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&sl.cand_ij, pairs * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&sl.cand_count, e->num_limbs * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&sl.conn, (size_t)e->num_limbs * e->max_peaks * 2 * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&sl.conn_score, (size_t)e->num_limbs * e->max_peaks * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&sl.conn_count, e->num_limbs * sizeof(int)));
+  const size_t jfloats = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3;
+  HIPCHK(e, hipMalloc((void**)&sl.joints, jfloats * sizeof(float)));
+  HIPCHK(e, hipMemset(sl.joints, 0, jfloats * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&sl.num_people, sizeof(int)));
+  HIPCHK(e, hipHostMalloc((void**)&sl.host_out, (jfloats + 4) * sizeof(float), hipHostMallocDefault));
+  for (int i = 0; i < 5; ++i) HIPCHK(e, hipEventCreate(&sl.ev[i]));
   return RTP_OK;
 }
 
@@ -677,46 +732,37 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   HIPCHK(e, hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
   HIPCHK(e, hipMalloc((void**)&cx.arena, e->arena_bytes));
   HIPCHK(e, hipMemset(cx.arena, 0, e->arena_bytes));
-  const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+  const size_t in_floats = (size_t)e->NI * 3 * e->cfg.net_h * e->cfg.net_w;
   HIPCHK(e, hipMalloc((void**)&cx.input, in_floats * sizeof(float)));
   HIPCHK(e, hipHostMalloc((void**)&cx.host_in, in_floats * sizeof(float), hipHostMallocDefault));
-  const size_t low_floats = (size_t)e->N * e->heat_channels * e->low_h * e->low_w;
+  const size_t low_floats = (size_t)e->NI * e->heat_channels * e->low_h * e->low_w;
   HIPCHK(e, hipMalloc((void**)&cx.lowres, low_floats * sizeof(float)));
   HIPCHK(e, hipMemset(cx.lowres, 0, low_floats * sizeof(float)));
-  const size_t res_floats = (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w;
-  HIPCHK(e, hipMalloc((void**)&cx.resized, res_floats * sizeof(float)));
-  const size_t peak_floats = (size_t)e->num_parts * (e->max_peaks + 1) * 3;
-  HIPCHK(e, hipMalloc((void**)&cx.peaks, peak_floats * sizeof(float)));
-  HIPCHK(e, hipMemset(cx.peaks, 0, peak_floats * sizeof(float)));
-  HIPCHK(e, hipMalloc((void**)&cx.strip_count, (size_t)e->num_parts * e->nstrips * sizeof(int)));
-  HIPCHK(e, hipMalloc((void**)&cx.strip_list, (size_t)e->num_parts * e->nstrips * e->max_peaks * sizeof(int)));
-  const size_t pairs = (size_t)e->num_limbs * e->max_peaks * e->max_peaks;
-  HIPCHK(e, hipMalloc((void**)&cx.cand_score, pairs * sizeof(float)));
-  HIPCHK(e, hipMalloc((void**)&cx.cand_ij, pairs * sizeof(int)));
-  HIPCHK(e, hipMalloc((void**)&cx.cand_count, e->num_limbs * sizeof(int)));
-  HIPCHK(e, hipMalloc((void**)&cx.conn, (size_t)e->num_limbs * e->max_peaks * 2 * sizeof(int)));
-  HIPCHK(e, hipMalloc((void**)&cx.conn_score, (size_t)e->num_limbs * e->max_peaks * sizeof(float)));
-  HIPCHK(e, hipMalloc((void**)&cx.conn_count, e->num_limbs * sizeof(int)));
-  const size_t jfloats = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3;
-  HIPCHK(e, hipMalloc((void**)&cx.joints, jfloats * sizeof(float)));
-  HIPCHK(e, hipMemset(cx.joints, 0, jfloats * sizeof(float)));
-  HIPCHK(e, hipMalloc((void**)&cx.num_people, sizeof(int)));
-  HIPCHK(e, hipHostMalloc((void**)&cx.host_out, (jfloats + 4) * sizeof(float), hipHostMallocDefault));
-  for (int i = 0; i < 6; ++i) HIPCHK(e, hipEventCreate(&cx.ev[i]));
+  for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.ev[i]));
+  cx.slot.resize(e->B);
+  for (int j = 0; j < e->B; ++j) {
+    int rc;
+    if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0))) return rc;
+  }
   return RTP_OK;
 }
 
 void free_ctx(Ctx& cx) {
   if (cx.stream) (void)hipStreamSynchronize(cx.stream);
-  void* dptrs[] = {cx.arena, cx.input, cx.lowres, cx.resized, cx.peaks, cx.strip_count, cx.strip_list, cx.cand_score, cx.cand_ij,
-                   cx.cand_count, cx.conn, cx.conn_score, cx.conn_count, cx.joints, cx.num_people};
+  for (Slot& sl : cx.slot) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    void* dptrs[] = {sl.resized, sl.peaks, sl.strip_count, sl.strip_list, sl.cand_score, sl.cand_ij, sl.cand_count, sl.conn, sl.conn_score,
+                     sl.conn_count, sl.joints, sl.num_people, sl.frame_dev, sl.disp_dev};
+    for (void* p : dptrs) if (p) (void)hipFree(p);
+    if (sl.frame_host) (void)hipHostFree(sl.frame_host);
+    if (sl.host_out) (void)hipHostFree(sl.host_out);
+    for (int i = 0; i < 5; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
+    if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
+  void* dptrs[] = {cx.arena, cx.input, cx.lowres};
   for (void* p : dptrs) if (p) (void)hipFree(p);
-  if (cx.frame_dev) (void)hipFree(cx.frame_dev);
-  if (cx.disp_dev) (void)hipFree(cx.disp_dev);
-  if (cx.frame_host) (void)hipHostFree(cx.frame_host);
   if (cx.host_in) (void)hipHostFree(cx.host_in);
-  if (cx.host_out) (void)hipHostFree(cx.host_out);
-  for (int i = 0; i < 6; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
+  for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
   for (auto ev : cx.dom_a) (void)hipEventDestroy(ev);
   for (auto ev : cx.dom_b) (void)hipEventDestroy(ev);
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
@@ -770,25 +816,59 @@ int build_prep_tables(rtp_engine* e) {
   return RTP_OK;
 }
 
-// raw u8 BGR frame (host) -> cx.input on the device
-int enqueue_preprocess(rtp_engine* e, Ctx& cx, const unsigned char* bgr, int w, int h, float* frame_scale) {
+// raw u8 BGR frame (host) -> frame slot sj of cx.input on the device
+int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr, int w, int h, float* frame_scale) {
+  Slot& sl = cx.slot[sj];
   const size_t fbytes = (size_t)w * h * 3;
-  if (fbytes > cx.frame_cap) {
+  if (fbytes > sl.frame_cap) {
     HIPCHK(e, hipStreamSynchronize(cx.stream));
-    if (cx.frame_dev) (void)hipFree(cx.frame_dev);
-    if (cx.frame_host) (void)hipHostFree(cx.frame_host);
-    cx.frame_dev = nullptr; cx.frame_host = nullptr; cx.frame_cap = 0;
-    HIPCHK(e, hipMalloc((void**)&cx.frame_dev, fbytes));
-    HIPCHK(e, hipHostMalloc((void**)&cx.frame_host, fbytes, hipHostMallocDefault));
-    cx.frame_cap = fbytes;
+    if (sl.frame_dev) (void)hipFree(sl.frame_dev);
+    if (sl.frame_host) (void)hipHostFree(sl.frame_host);
+    sl.frame_dev = nullptr; sl.frame_host = nullptr; sl.frame_cap = 0;
+    HIPCHK(e, hipMalloc((void**)&sl.frame_dev, fbytes));
+    HIPCHK(e, hipHostMalloc((void**)&sl.frame_host, fbytes, hipHostMallocDefault));
+    sl.frame_cap = fbytes;
   }
-  if (!cx.disp_dev) HIPCHK(e, hipMalloc((void**)&cx.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3));
+  if (!sl.disp_dev) HIPCHK(e, hipMalloc((void**)&sl.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3));
   const double s = rtp_display_fit_scale(w, h, e->cfg.disp_w, e->cfg.disp_h);
   if (frame_scale) *frame_scale = (float)s;
-  memcpy(cx.frame_host, bgr, fbytes);
-  HIPCHK(e, hipMemcpyAsync(cx.frame_dev, cx.frame_host, fbytes, hipMemcpyHostToDevice, cx.stream));
-  HIPCHK(e, launch_warp(cx.frame_dev, w, h, 1.0 / s, e->warp_tab, cx.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
-  HIPCHK(e, launch_area_pad(cx.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, cx.input, e->cfg.net_w, e->cfg.net_h, cx.stream));
+  memcpy(sl.frame_host, bgr, fbytes);
+  float* dst = cx.input + (size_t)sj * e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+  HIPCHK(e, hipMemcpyAsync(sl.frame_dev, sl.frame_host, fbytes, hipMemcpyHostToDevice, cx.stream));
+  HIPCHK(e, launch_warp(sl.frame_dev, w, h, 1.0 / s, e->warp_tab, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
+  HIPCHK(e, launch_area_pad(sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.stream));
+  return RTP_OK;
+}
+
+// ---- batching: frames are staged into the open context; a full batch is launched at once ----------
+int open_slot(rtp_engine* e, int* ci, int* sj) {
+  if (e->open_ctx < 0) {
+    for (size_t i = 0; i < e->ctx.size() && e->open_ctx < 0; ++i) {
+      Ctx& c = e->ctx[i];
+      bool idle = !c.launched && c.filled == 0;
+      for (Slot& s : c.slot) idle = idle && !s.busy;
+      if (idle) e->open_ctx = (int)i;
+    }
+    if (e->open_ctx < 0) return fail(e, RTP_EAGAIN, "all %zu batch contexts (%d frames each) are busy", e->ctx.size(), e->B);
+  }
+  *ci = e->open_ctx;
+  *sj = e->ctx[e->open_ctx].filled;
+  return RTP_OK;
+}
+int launch_open(rtp_engine* e) {
+  if (e->open_ctx < 0) return RTP_OK;
+  Ctx& cx = e->ctx[e->open_ctx];
+  e->open_ctx = -1;
+  if (cx.filled == 0) return RTP_OK;
+  return launch_batch(e, cx, cx.filled, cx.input);
+}
+int commit_slot(rtp_engine* e, int ci, int sj, uint64_t tag) {
+  Ctx& cx = e->ctx[ci];
+  cx.slot[sj].tag = tag;
+  cx.slot[sj].busy = true;
+  cx.filled = sj + 1;
+  e->fifo.push_back(ci * 64 + sj);
+  if (cx.filled == e->B) return launch_open(e);
   return RTP_OK;
 }
 
@@ -813,6 +893,7 @@ int rtp_config_default(rtp_config* cfg) {
   cfg->disp_w = 1280; cfg->disp_h = 720;
   cfg->precision = RTP_PREC_FP16;
   cfg->frames_in_flight = 2;
+  cfg->batch_frames = 1;
   return RTP_OK;
 }
 
@@ -835,7 +916,8 @@ int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
   if (!cfg || !out) return fail(nullptr, RTP_EINVAL, "null argument");
   *out = nullptr;
   if (cfg->num_scales < 1 || cfg->num_scales > 16) return fail(nullptr, RTP_EINVAL, "num_scales %d out of range", cfg->num_scales);
-  if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 16) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
+  if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 64) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
+  if (cfg->batch_frames < 0 || cfg->batch_frames > 16) return fail(nullptr, RTP_EINVAL, "batch_frames %d out of range", cfg->batch_frames);
   if (cfg->precision != RTP_PREC_FP16 && cfg->precision != RTP_PREC_FP32) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
   if (cfg->disp_w < 1 || cfg->disp_h < 1) return fail(nullptr, RTP_EINVAL, "bad display resolution");
   // CHECK_LE(target_width, NET_RESOLUTION_WIDTH) (rtpose.cpp:363): every scale must fit the net input
@@ -858,6 +940,8 @@ int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
   e->prec = cfg->precision;
   e->elem = cfg->precision == RTP_PREC_FP16 ? 2 : 4;
   e->N = cfg->num_scales;
+  e->B = cfg->batch_frames < 1 ? 1 : cfg->batch_frames;
+  e->NI = e->N * e->B;
   e->start_scale = cfg->start_scale;
   e->scale_gap = cfg->scale_gap;
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
@@ -914,7 +998,7 @@ int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
   }
   for (size_t i = 0; i < e->convs.size(); ++i)
     if ((rc = upload_conv_weights(e, (int)i))) return bail(rc);
-  e->ctx.resize(cfg->frames_in_flight);
+  e->ctx.resize((cfg->frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0));  // batches in flight (+1 being filled)
   for (auto& c : e->ctx)
     if ((rc = alloc_ctx(e, c))) return bail(rc);
   if ((rc = build_prep_tables(e))) return bail(rc);
@@ -925,6 +1009,7 @@ int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
     hipError_t s = hipMemsetAsync(cx.input, 0, in_floats * sizeof(float), cx.stream);
     if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "hipMemsetAsync failed"));
     if ((rc = enqueue_frame(e, cx, cx.input))) return bail(rc);
+    cx.launched = false;
     s = hipStreamSynchronize(cx.stream);
     if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s)));
   }
@@ -974,69 +1059,66 @@ int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap) {
   return RTP_OK;
 }
 
-static int pick_ctx(rtp_engine* e) {
-  for (size_t i = 0; i < e->ctx.size(); ++i)
-    if (!e->ctx[i].busy) return (int)i;
-  return -1;
-}
-
 int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if (!e || !d_in) return RTP_EINVAL;
-  int rc;
+  int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
-  const int ci = pick_ctx(e);
-  if (ci < 0) return fail(e, RTP_EAGAIN, "all %zu frame contexts are busy", e->ctx.size());
+  if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
-  if ((rc = enqueue_frame(e, cx, d_in))) return rc;
-  cx.tag = tag;
-  cx.busy = true;
-  e->fifo.push_back(ci);
-  return RTP_OK;
+  const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
+  if (e->B == 1) {  // no staging copy: the conv stack reads the caller's tensor
+    cx.slot[0].tag = tag;
+    cx.slot[0].busy = true;
+    cx.filled = 1;
+    e->fifo.push_back(ci * 64);
+    e->open_ctx = -1;
+    return launch_batch(e, cx, 1, d_in);
+  }
+  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, d_in, bytes, hipMemcpyDeviceToDevice, cx.stream));
+  return commit_slot(e, ci, sj, tag);
 }
 
 int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   if (!e || !h_in) return RTP_EINVAL;
-  int rc;
+  int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
-  const int ci = pick_ctx(e);
-  if (ci < 0) return fail(e, RTP_EAGAIN, "all %zu frame contexts are busy", e->ctx.size());
+  if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
-  memcpy(cx.host_in, h_in, bytes);
-  HIPCHK(e, hipMemcpyAsync(cx.input, cx.host_in, bytes, hipMemcpyHostToDevice, cx.stream));
-  if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
-  cx.tag = tag;
-  cx.busy = true;
-  e->fifo.push_back(ci);
-  return RTP_OK;
+  memcpy((char*)cx.host_in + sj * bytes, h_in, bytes);
+  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, cx.stream));
+  return commit_slot(e, ci, sj, tag);
 }
 
 // Replaces the producer's per-frame OpenCV work + H2D (rtpose.cpp:322-368, 1131-1133): raw u8 BGR frame
 // in, pre-processing on the device (preproc.hip), then the same frame path as rtp_submit.
 int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint64_t tag, float* frame_scale) {
   if (!e || !bgr || w < 1 || h < 1) return RTP_EINVAL;
-  int rc;
+  int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
-  const int ci = pick_ctx(e);
-  if (ci < 0) return fail(e, RTP_EAGAIN, "all %zu frame contexts are busy", e->ctx.size());
+  if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   if (e->gpu_prep_ok) {
-    if ((rc = enqueue_preprocess(e, cx, bgr, w, h, frame_scale))) return rc;
+    if ((rc = enqueue_preprocess(e, cx, sj, bgr, w, h, frame_scale))) return rc;
   } else {  // a pyramid level would have to be enlarged: host restatement (linear fallback) + H2D
     const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
+    float* hin = (float*)((char*)cx.host_in + sj * bytes);
     rc = rtp_preprocess_frame(bgr, w, h, e->cfg.disp_w, e->cfg.disp_h, e->cfg.net_w, e->cfg.net_h, e->N, e->start_scale, e->scale_gap,
-                              cx.host_in, nullptr, frame_scale);
+                              hin, nullptr, frame_scale);
     if (rc) return fail(e, rc, "pre-processing failed (a scale does not fit the net resolution?)");
-    HIPCHK(e, hipMemcpyAsync(cx.input, cx.host_in, bytes, hipMemcpyHostToDevice, cx.stream));
+    HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, hin, bytes, hipMemcpyHostToDevice, cx.stream));
   }
-  if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
-  cx.tag = tag;
-  cx.busy = true;
-  e->fifo.push_back(ci);
-  return RTP_OK;
+  return commit_slot(e, ci, sj, tag);
 }
 
-static int need_idle(rtp_engine* e);
+// Launch a partially filled batch now (end of stream, or a latency-sensitive caller).
+int rtp_flush(rtp_engine* e) {
+  if (!e) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  return launch_open(e);
+}
+
 // Parity tap: the device pre-processing alone (net input and display image back on the host).
 int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, float* net_input, unsigned char* display_bgr, float* frame_scale) {
   int rc;
@@ -1044,41 +1126,51 @@ int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, 
   if (!bgr || w < 1 || h < 1) return RTP_EINVAL;
   if (!e->gpu_prep_ok) return fail(e, RTP_EINVAL, "device pre-processing unavailable for this configuration (a level would be enlarged)");
   Ctx& cx = e->ctx[0];
-  if ((rc = enqueue_preprocess(e, cx, bgr, w, h, frame_scale))) return rc;
+  if ((rc = enqueue_preprocess(e, cx, 0, bgr, w, h, frame_scale))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
   if (net_input) HIPCHK(e, hipMemcpy(net_input, cx.input, (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
-  if (display_bgr) HIPCHK(e, hipMemcpy(display_bgr, cx.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3, hipMemcpyDeviceToHost));
+  if (display_bgr) HIPCHK(e, hipMemcpy(display_bgr, cx.slot[0].disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3, hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 
 int rtp_in_flight(const rtp_engine* e) { return e ? (int)e->fifo.size() : 0; }
+
+static void stage_ms(rtp_engine* e, Ctx& cx, Slot& sl) {
+  hipEvent_t a[5] = {cx.ev[0], sl.ev[0], sl.ev[1], sl.ev[2], cx.ev[0]};
+  hipEvent_t b[5] = {cx.ev[1], sl.ev[1], sl.ev[2], sl.ev[3], sl.ev[4]};
+  for (int i = 0; i < 5; ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a[i], b[i]);
+    e->last_ms[i] = ms;
+  }
+}
 
 int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) {
   if (!e) return RTP_EINVAL;
   if (e->fifo.empty()) return fail(e, RTP_EAGAIN, "nothing in flight");
   int rc;
   if ((rc = use_device(e))) return rc;
-  const int ci = e->fifo.front();
+  const int ci = e->fifo.front() / 64, sj = e->fifo.front() % 64;
   Ctx& cx = e->ctx[ci];
-  HIPCHK(e, hipEventSynchronize(cx.ev[5]));
+  Slot& sl = cx.slot[sj];
+  if (!cx.launched && (rc = launch_open(e))) return rc;  // the oldest frame sits in a partial batch
+  HIPCHK(e, hipEventSynchronize(sl.ev[4]));
   e->fifo.pop_front();
-  cx.busy = false;
+  sl.busy = false;
+  bool any = false;
+  for (Slot& s : cx.slot) any = any || s.busy;
+  if (!any) { cx.launched = false; cx.filled = 0; }
   int n;
-  memcpy(&n, cx.host_out, sizeof(int));
-  if (tag) *tag = cx.tag;
-
-  for (int i = 0; i < 5; ++i) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, cx.ev[i == 4 ? 0 : i], cx.ev[i == 4 ? 5 : i + 1]);
-    e->last_ms[i] = ms;
-  }
+  memcpy(&n, sl.host_out, sizeof(int));
+  if (tag) *tag = sl.tag;
+  stage_ms(e, cx, sl);
   if (n < 0) {
     if (num_people) *num_people = 0;
     return fail(e, RTP_ERANGE, "connect: a PAF sample coordinate fell outside the net resolution (the reference CHECK-fails here, rtpose.cpp:928)");
   }
   if (n > RTP_MAX_PEOPLE) n = RTP_MAX_PEOPLE;
   if (num_people) *num_people = n;
-  if (joints) memcpy(joints, cx.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
+  if (joints) memcpy(joints, sl.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
   return RTP_OK;
 }
 
@@ -1105,18 +1197,16 @@ int rtp_forward_debug(rtp_engine* e, const float* h_in, float* lowres, float* re
   if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
   if (lowres) HIPCHK(e, hipMemcpy(lowres, cx.lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyDeviceToHost));
-  if (resized) HIPCHK(e, hipMemcpy(resized, cx.resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
-  if (peaks) HIPCHK(e, hipMemcpy(peaks, cx.peaks, (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  Slot& sl = cx.slot[0];
+  cx.launched = false;
+  if (resized) HIPCHK(e, hipMemcpy(resized, sl.resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
+  if (peaks) HIPCHK(e, hipMemcpy(peaks, sl.peaks, (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float), hipMemcpyDeviceToHost));
   int n;
-  memcpy(&n, cx.host_out, sizeof(int));
-  for (int i = 0; i < 5; ++i) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, cx.ev[i == 4 ? 0 : i], cx.ev[i == 4 ? 5 : i + 1]);
-    e->last_ms[i] = ms;
-  }
+  memcpy(&n, sl.host_out, sizeof(int));
+  stage_ms(e, cx, sl);
   if (n < 0) { if (num_people) *num_people = 0; return fail(e, RTP_ERANGE, "connect: PAF sample coordinate out of range"); }
   if (num_people) *num_people = n;
-  if (joints) memcpy(joints, cx.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
+  if (joints) memcpy(joints, sl.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
   return RTP_OK;
 }
 
@@ -1127,7 +1217,7 @@ int rtp_forward_heatmaps(rtp_engine* e, const float* h_in, float* lowres) {
   Ctx& cx = e->ctx[0];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   HIPCHK(e, hipMemcpy(cx.input, h_in, bytes, hipMemcpyHostToDevice));
-  if ((rc = run_frame_stack(e, cx, cx.input))) return rc;
+  if ((rc = run_frame_stack(e, cx, cx.input, e->N))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
   HIPCHK(e, hipMemcpy(lowres, cx.lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyDeviceToHost));
   return RTP_OK;
@@ -1141,7 +1231,7 @@ int rtp_resize(rtp_engine* e, const float* lowres, float* resized) {
   HIPCHK(e, hipMemcpy(cx.lowres, lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyHostToDevice));
   if ((rc = run_resize(e, cx))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
-  HIPCHK(e, hipMemcpy(resized, cx.resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(resized, cx.slot[0].resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 
@@ -1151,11 +1241,11 @@ int rtp_nms(rtp_engine* e, const float* resized, float* peaks) {
   if (!resized || !peaks) return RTP_EINVAL;
   Ctx& cx = e->ctx[0];
   const size_t pbytes = (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float);
-  HIPCHK(e, hipMemcpy(cx.resized, resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(cx.peaks, peaks, pbytes, hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cx.slot[0].resized, resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cx.slot[0].peaks, peaks, pbytes, hipMemcpyHostToDevice));
   if ((rc = run_nms(e, cx))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
-  HIPCHK(e, hipMemcpy(peaks, cx.peaks, pbytes, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(peaks, cx.slot[0].peaks, pbytes, hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 
@@ -1164,15 +1254,15 @@ int rtp_connect(rtp_engine* e, const float* resized, const float* peaks, float* 
   if ((rc = need_idle(e))) return rc;
   if (!resized || !peaks) return RTP_EINVAL;
   Ctx& cx = e->ctx[0];
-  HIPCHK(e, hipMemcpy(cx.resized, resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(cx.peaks, peaks, (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cx.slot[0].resized, resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cx.slot[0].peaks, peaks, (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float), hipMemcpyHostToDevice));
   if ((rc = run_connect(e, cx))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
   int n = 0;
-  HIPCHK(e, hipMemcpy(&n, cx.num_people, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(&n, cx.slot[0].num_people, sizeof(int), hipMemcpyDeviceToHost));
   if (n < 0) { if (num_people) *num_people = 0; return fail(e, RTP_ERANGE, "connect: PAF sample coordinate out of range"); }
   if (num_people) *num_people = n;
-  if (joints && n > 0) HIPCHK(e, hipMemcpy(joints, cx.joints, (size_t)n * e->num_parts * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (joints && n > 0) HIPCHK(e, hipMemcpy(joints, cx.slot[0].joints, (size_t)n * e->num_parts * 3 * sizeof(float), hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 
@@ -1192,7 +1282,8 @@ int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int sh
   auto it = e->blob_tensor.find(name);
   if (it == e->blob_tensor.end()) return fail(e, RTP_EINVAL, "Unknown blob name %s", name);  // net.cpp blob_by_name warning
   const Tensor& t = e->tensors[it->second];
-  const Geom& g = e->geom[t.level];
+  Geom g = e->geom[t.level];
+  g.N = e->N;  // the taps run one frame (slot 0 of the batch)
   const size_t n = (size_t)g.N * t.C * g.H * g.W;
   if (shape) { shape[0] = g.N; shape[1] = t.C; shape[2] = g.H; shape[3] = g.W; }
   if (!out) return RTP_OK;
@@ -1298,8 +1389,8 @@ int rtp_debug_connect_stats(rtp_engine* e, int* cand_count, int* conn_count) {
   int rc;
   if ((rc = need_idle(e))) return rc;
   Ctx& cx = e->ctx[0];
-  if (cand_count) HIPCHK(e, hipMemcpy(cand_count, cx.cand_count, e->num_limbs * sizeof(int), hipMemcpyDeviceToHost));
-  if (conn_count) HIPCHK(e, hipMemcpy(conn_count, cx.conn_count, e->num_limbs * sizeof(int), hipMemcpyDeviceToHost));
+  if (cand_count) HIPCHK(e, hipMemcpy(cand_count, cx.slot[0].cand_count, e->num_limbs * sizeof(int), hipMemcpyDeviceToHost));
+  if (conn_count) HIPCHK(e, hipMemcpy(conn_count, cx.slot[0].conn_count, e->num_limbs * sizeof(int), hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 
@@ -1380,6 +1471,8 @@ long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
   e->prec = cfg->precision;
   e->elem = cfg->precision == RTP_PREC_FP16 ? 2 : 4;
   e->N = cfg->num_scales;
+  e->B = cfg->batch_frames < 1 ? 1 : cfg->batch_frames;
+  e->NI = e->N * e->B;
   if (cfg->proto_path) {
     std::ifstream f(cfg->proto_path);
     std::stringstream ss;
@@ -1410,7 +1503,7 @@ long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
       o << "step conv " << A.name;
       if (s.b >= 0) o << " + " << e->convs[s.b].name;
       o << " k " << A.k << " cin_p " << A.Cin_p << " cout " << A.cout << " coutp " << A.CoutP << " relu " << A.relu << " tile " << ci.BM << "x" << ci.BN
-        << " rowb " << A.rowb << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->N * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
+        << " rowb " << A.rowb << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->NI * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
       for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; gflop += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9; }
     }
   }
@@ -1444,7 +1537,7 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     if (e->dominant_step >= 0) {
       const Step& s = e->steps[e->dominant_step];
       const Geom& g = e->geom[e->convs[s.a].level];
-      for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N; }
+      for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->NI; }
     }
     *flops_per_launch = fl;
   }
@@ -1470,9 +1563,9 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   const Step& s = e->steps[e->dominant_step];
   const ConvOp& A = e->convs[s.a];
   const Geom& g = e->geom[A.level];
-  for (int i = 0; i < 3; ++i) if ((rc = launch_conv_step(e, cx, s))) return rc;
+  for (int i = 0; i < 3; ++i) if ((rc = launch_conv_step(e, cx, s, e->NI))) return rc;
   HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
-  for (int i = 0; i < iters; ++i) if ((rc = launch_conv_step(e, cx, s))) return rc;
+  for (int i = 0; i < iters; ++i) if ((rc = launch_conv_step(e, cx, s, e->NI))) return rc;
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
   HIPCHK(e, hipEventSynchronize(cx.ev[1]));
   float ms = 0.f;
@@ -1480,7 +1573,7 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   if (avg_ms) *avg_ms = ms / iters;
   const int nprob = s.b >= 0 ? 2 : 1;
   double fl = 0;
-  for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N; }
+  for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->NI; }
   (void)nprob;
   if (flops_per_launch) *flops_per_launch = fl;
   return RTP_OK;

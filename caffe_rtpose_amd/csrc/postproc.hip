@@ -260,178 +260,231 @@ __constant__ int kMpiMap[28] = {16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 
 
 #define CONNECT_ERR_RANGE (-34)
 
-// One workgroup per limb k.
-// Phase 1: PAF line integral of every (i,j) candidate pair in the reference's loop order (i outer,
-//   j inner; rtpose.cpp:897-951 / :611-651); the 10 sample addresses are computed first so that
-//   the 20 gathers of a pair are in flight together; survivors are compacted in loop order.
-// Phase 2: order the survivors as std::sort(.., ColumnCompare) would (rtpose.cpp:953-954).  If all
-//   scores are distinct the sorted order is unique, so a parallel rank sort gives it; if any two
-//   compare equal (or a NaN is present) lane 0 runs the libstdc++-exact replica instead.
-// Phase 3 (lane 0): greedy assignment (:956-980).
-__global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int cap = p.max_peaks * p.max_peaks;
-  Cand* cands = (Cand*)lds_raw;   // [cap]
-  Cand* sorted = cands + cap;     // [cap]
-  __shared__ int wave_cnt[4];
-  __shared__ int running;
-  __shared__ int err;
-  __shared__ int tie;
-  const int k = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// connectLimbs* in three kernels (all bit-exact restatements; -ffp-contract=off):
+//  connect_pairs_kernel    grid (ceil(max_peaks^2/256), limbs): the PAF line integral of every (i,j)
+//      candidate pair (rtpose.cpp:897-951 / :611-651), one pair per thread, result to global
+//      scratch in the reference's loop order q = (i-1)*nB + (j-1): cand_ij[q] = 0 when the pair fails.
+//  connect_match_kernel    one workgroup per limb: compacts the survivors in loop order, orders them
+//      as std::sort(.., ColumnCompare) would (:953-954) and runs the greedy assignment (:956-980).
+//      If all scores are distinct the sorted order is unique, so a bitonic sort on the 64-bit key
+//      (score descending, loop order ascending) gives it.  std::sort leaves the relative order of
+//      EQUAL scores implementation-defined, but that only matters if two tied candidates are both
+//      still free when the greedy scan reaches them: the scan detects exactly that case (and NaNs)
+//      and only then lane 0 runs the libstdc++-exact replica.
+//  connect_assemble_kernel one workgroup: person assembly + emission.
+// Short kernels with <= 56 KiB of LDS: a convolution workgroup of another frame can share the CU.
+__device__ __forceinline__ void limb_setup(const ConnectParams& p, int k, const float*& candA, const float*& candB, int& nA, int& nB) {
   const bool coco = p.model == 0;
   const int* limbSeq = coco ? kCocoLimb : kMpiLimb;
-  const int* mapIdx = coco ? kCocoMap : kMpiMap;
-  const int NW = p.net_w, NH = p.net_h;
   const int peaks_offset = 3 * (p.max_peaks + 1);
-  const float* map_x = p.heat + (long)mapIdx[2 * k] * NH * NW;
-  const float* map_y = p.heat + (long)mapIdx[2 * k + 1] * NH * NW;
-  const float* candA = p.peaks + limbSeq[2 * k] * peaks_offset;
-  const float* candB = p.peaks + limbSeq[2 * k + 1] * peaks_offset;
-  int nA = (int)candA[0], nB = (int)candB[0];
+  candA = p.peaks + limbSeq[2 * k] * peaks_offset;
+  candB = p.peaks + limbSeq[2 * k + 1] * peaks_offset;
+  nA = (int)candA[0];
+  nB = (int)candB[0];
   if (nA > p.max_peaks) nA = p.max_peaks;  // defined-behaviour clamp (see oracle NOTE)
   if (nB > p.max_peaks) nB = p.max_peaks;
-  if (tid == 0) { running = 0; err = 0; tie = 0; }
+}
+
+__global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p) {
+  const int k = blockIdx.y;
+  const int cap = p.max_peaks * p.max_peaks;
+  const bool coco = p.model == 0;
+  const int* mapIdx = coco ? kCocoMap : kMpiMap;
+  const int NW = p.net_w, NH = p.net_h;
+  const float* map_x = p.heat + (long)mapIdx[2 * k] * NH * NW;
+  const float* map_y = p.heat + (long)mapIdx[2 * k + 1] * NH * NW;
+  const float *candA, *candB;
+  int nA, nB;
+  limb_setup(p, k, candA, candB, nA, nB);
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nA * nB) return;
+  const int num_inter = 10;
+  int pass = 0;
+  float conn_score = 0.f;
+  const int i = q / nB + 1, j = q % nB + 1;
+  const float s_x = candA[i * 3];
+  const float s_y = candA[i * 3 + 1];
+  const float d_x = candB[j * 3] - candA[i * 3];
+  const float d_y = candB[j * 3 + 1] - candA[i * 3 + 1];
+  float norm_vec;
+  if (coco) norm_vec = sqrtf(d_x * d_x + d_y * d_y);
+  else norm_vec = (float)sqrt((double)d_x * (double)d_x + (double)d_y * (double)d_y);  // pow(d,2) in double
+  if (!(norm_vec < 1e-6)) {
+    const float vec_x = d_x / norm_vec;
+    const float vec_y = d_y / norm_vec;
+    int idxs[10];
+    bool bad = false;
+#pragma unroll
+    for (int lm = 0; lm < num_inter; lm++) {
+      int my = (int)roundf(s_y + lm * d_y / num_inter);
+      int mx = (int)roundf(s_x + lm * d_x / num_inter);
+      if (coco) {
+        if (mx >= NW) mx = NW - 1;
+        if (my >= NH) my = NH - 1;
+      }
+      if (mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; mx = 0; my = 0; }
+      idxs[lm] = my * NW + mx;
+    }
+    float px[10], py[10];
+#pragma unroll
+    for (int lm = 0; lm < num_inter; lm++) { px[lm] = map_x[idxs[lm]]; py[lm] = map_y[idxs[lm]]; }
+    float sum = 0;
+    int count = 0;
+#pragma unroll
+    for (int lm = 0; lm < num_inter; lm++) {
+      const float score = (vec_x * px[lm] + vec_y * py[lm]);
+      if (score > p.inter_threshold) {
+        sum = sum + score;
+        count++;
+      }
+    }
+    if (bad) *p.num_people = CONNECT_ERR_RANGE;  // the reference CHECK-fails here (rtpose.cpp:928)
+    else if (count > p.inter_min_above) {
+      pass = 1;
+      conn_score = sum / count;
+    }
+  }
+  p.cand_score[(long)k * cap + q] = conn_score;
+  p.cand_ij[(long)k * cap + q] = pass ? ((i << 16) | j) : 0;
+}
+
+// 64-bit sort key: ascending key order == (score descending, loop order ascending)
+__device__ __forceinline__ unsigned long long match_key(float score, int ord, int i, int j) {
+  unsigned int u = __float_as_uint(score);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotonic in the float order
+  return ((unsigned long long)(~u) << 32) | (unsigned int)((ord << 14) | (i << 7) | j);
+}
+__device__ __forceinline__ float key_score(unsigned long long key) {
+  unsigned int u = ~(unsigned int)(key >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned long long* keys = (unsigned long long*)lds_raw;  // [pow2 >= survivors]
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  __shared__ int flags;  // 1: NaN score seen   2: greedy scan met an ambiguous tie
+  __shared__ int s_cnt;
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cap = p.max_peaks * p.max_peaks;
+  const bool coco = p.model == 0;
+  const int* limbSeq = coco ? kCocoLimb : kMpiLimb;
+  const int peaks_offset = 3 * (p.max_peaks + 1);
+  const float *candA, *candB;
+  int nA, nB;
+  limb_setup(p, k, candA, candB, nA, nB);
+  if (tid == 0) { running = 0; flags = 0; s_cnt = 0; }
   __syncthreads();
   if (nA == 0 || nB == 0) {
     if (tid == 0) { p.cand_count[k] = 0; p.conn_count[k] = 0; }
     return;
   }
   const int npairs = nA * nB;
-  const int num_inter = 10;
-  for (int base = 0; base < npairs; base += 256) {
-    const int q = base + tid;
-    int pass = 0;
-    float conn_score = 0.f;
-    int ij = 0;
-    if (q < npairs) {
-      const int i = q / nB + 1, j = q % nB + 1;
-      ij = (i << 16) | j;
-      const float s_x = candA[i * 3];
-      const float s_y = candA[i * 3 + 1];
-      const float d_x = candB[j * 3] - candA[i * 3];
-      const float d_y = candB[j * 3 + 1] - candA[i * 3 + 1];
-      float norm_vec;
-      if (coco) norm_vec = sqrtf(d_x * d_x + d_y * d_y);
-      else norm_vec = (float)sqrt((double)d_x * (double)d_x + (double)d_y * (double)d_y);  // pow(d,2) in double
-      if (!(norm_vec < 1e-6)) {
-        const float vec_x = d_x / norm_vec;
-        const float vec_y = d_y / norm_vec;
-        int idxs[10];
-        bool bad = false;
-#pragma unroll
-        for (int lm = 0; lm < num_inter; lm++) {
-          int my = (int)roundf(s_y + lm * d_y / num_inter);
-          int mx = (int)roundf(s_x + lm * d_x / num_inter);
-          if (coco) {
-            if (mx >= NW) mx = NW - 1;
-            if (my >= NH) my = NH - 1;
-          }
-          if (mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; mx = 0; my = 0; }
-          idxs[lm] = my * NW + mx;
-        }
-        float px[10], py[10];
-#pragma unroll
-        for (int lm = 0; lm < num_inter; lm++) { px[lm] = map_x[idxs[lm]]; py[lm] = map_y[idxs[lm]]; }
-        float sum = 0;
-        int count = 0;
-#pragma unroll
-        for (int lm = 0; lm < num_inter; lm++) {
-          const float score = (vec_x * px[lm] + vec_y * py[lm]);
-          if (score > p.inter_threshold) {
-            sum = sum + score;
-            count++;
-          }
-        }
-        if (bad) err = 1;
-        else if (count > p.inter_min_above) {
-          pass = 1;
-          conn_score = sum / count;
-        }
-      }
+  const float* gs = p.cand_score + (long)k * cap;
+  const int* gij = p.cand_ij + (long)k * cap;
+  // ---- survivors, compacted in loop order
+  auto compact = [&](auto&& put) {
+    for (int base = 0; base < npairs; base += 256) {
+      const int q = base + tid;
+      int ij = 0;
+      float sc = 0.f;
+      if (q < npairs) { ij = gij[q]; sc = gs[q]; }
+      const unsigned long long bal = __ballot(ij != 0);
+      if (lane == 0) wave_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int before = running;
+      for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+      const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (ij) put(ord, sc, ij);
+      __syncthreads();
+      if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
     }
-    const unsigned long long bal = __ballot(pass);
-    if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int before = running;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (pass) { cands[ord].score = conn_score; cands[ord].ij = ij; }
-    __syncthreads();
-    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
-  }
+  };
+  compact([&](int ord, float sc, int ij) {
+    if (!(sc == sc)) flags = 1;  // NaN breaks the ordering: force the exact path
+    keys[ord] = match_key(sc, ord, ij >> 16, ij & 0xffff);
+  });
   const int nc = running;
-  // ---- phase 2: STABLE parallel rank sort: position = #greater + #equal-with-smaller-index.
-  // For distinct scores this is the unique sorted order; equal scores are handled in phase 3.
-  for (int i = tid; i < nc; i += 256) {
-    const float ki = cands[i].score;
-    int rank = 0;
-    bool nan = !(ki == ki);
-    for (int j = 0; j < nc; ++j) {
-      const float kj = cands[j].score;
-      rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
-    }
-    if (nan) tie = 2;  // NaN breaks the ordering: force the exact path
-    else sorted[rank] = cands[i];
-  }
+  int n2 = 64;
+  while (n2 < nc) n2 <<= 1;
+  for (int t = nc + tid; t < n2; t += 256) keys[t] = ~0ull;
   __syncthreads();
-  if (wave != 0) return;
-  // ---- phase 3 (wave 0): greedy assignment (:956-980), 64 sorted rows per step.
-  // std::sort leaves the relative order of EQUAL scores implementation-defined, but that order only
-  // matters if two tied candidates are both still free (i and j unused) when the scan reaches
-  // them.  The scan detects exactly that case and only then falls back to the libstdc++ replica.
+  // ---- bitonic sort, ascending keys
+  for (int kk = 2; kk <= n2; kk <<= 1) {
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      for (int t = tid; t < (n2 >> 1); t += 256) {
+        const int a = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+        const int b = a | jj;
+        const unsigned long long ka = keys[a], kb = keys[b];
+        const bool up = (a & kk) == 0;
+        if ((ka > kb) == up) { keys[a] = kb; keys[b] = ka; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- greedy assignment (:956-980) on wave 0, 64 sorted rows per step
   const int num = nA < nB ? nA : nB;
   int* conn = p.conn + (long)k * p.max_peaks * 2;
   float* cs = p.conn_score + (long)k * p.max_peaks;
   const int partA_off = limbSeq[2 * k] * peaks_offset, partB_off = limbSeq[2 * k + 1] * peaks_offset;
-  bool ambiguous = (tie == 2);
-  int cnt = 0;
-  if (!ambiguous) {
-    unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};  // wave-uniform copies
-    for (int base = 0; base < nc && cnt < num && !ambiguous; base += 64) {
-      const int row = base + lane;
-      Cand c; c.score = 0.f; c.ij = 0x00010001;
-      if (row < nc) c = sorted[row];
-      const int i = c.ij >> 16, j = c.ij & 0xffff;
-      unsigned long long done = 0;  // lanes of this chunk already decided
-      while (cnt < num) {
-        const bool free_ = row < nc && !((done >> lane) & 1) && !((occA[(i - 1) >> 6] >> ((i - 1) & 63)) & 1) &&
-                           !((occB[(j - 1) >> 6] >> ((j - 1) & 63)) & 1);
-        const unsigned long long bal = __ballot(free_);
-        if (!bal) break;
-        const int first = __ffsll((long long)bal) - 1;
-        const float sc = __shfl(c.score, first);
-        const int wi = __shfl(i, first), wj = __shfl(j, first);
-        // any OTHER free row with the same score (later in this chunk or in the following rows)?
-        bool amb = __any(free_ && lane != first && c.score == sc);
-        if (!amb) {
-          // tied rows may continue past this chunk
-          for (int r2 = base + 64; r2 < nc; ++r2) {
-            const Cand t2 = sorted[r2];
-            if (!(t2.score == sc)) break;
-            const int i2 = t2.ij >> 16, j2 = t2.ij & 0xffff;
-            if (!((occA[(i2 - 1) >> 6] >> ((i2 - 1) & 63)) & 1) && !((occB[(j2 - 1) >> 6] >> ((j2 - 1) & 63)) & 1)) { amb = true; break; }
+  if (wave == 0) {
+    bool ambiguous = flags != 0;
+    int cnt = 0;
+    if (!ambiguous) {
+      unsigned long long occA[2] = {0, 0}, occB[2] = {0, 0};  // wave-uniform copies (max_peaks <= 127)
+      for (int base = 0; base < nc && cnt < num && !ambiguous; base += 64) {
+        const int row = base + lane;
+        const unsigned long long key = row < nc ? keys[row] : 0ull;
+        const float score = key_score(key);
+        const int i = row < nc ? (int)((key >> 7) & 127) : 1, j = row < nc ? (int)(key & 127) : 1;
+        unsigned long long done = 0;  // lanes of this chunk already decided
+        while (cnt < num) {
+          const bool free_ = row < nc && !((done >> lane) & 1) && !((occA[(i - 1) >> 6] >> ((i - 1) & 63)) & 1) &&
+                             !((occB[(j - 1) >> 6] >> ((j - 1) & 63)) & 1);
+          const unsigned long long bal = __ballot(free_);
+          if (!bal) break;
+          const int first = __ffsll((long long)bal) - 1;
+          const float sc = __shfl(score, first);
+          const int wi = __shfl(i, first), wj = __shfl(j, first);
+          // any OTHER free row with the same score (later in this chunk or in the following rows)?
+          bool amb = __any(free_ && lane != first && score == sc);
+          if (!amb) {
+            for (int r2 = base + 64; r2 < nc; ++r2) {  // tied rows may continue past this chunk
+              const unsigned long long k2 = keys[r2];
+              if (!(key_score(k2) == sc)) break;
+              const int i2 = (int)((k2 >> 7) & 127), j2 = (int)(k2 & 127);
+              if (!((occA[(i2 - 1) >> 6] >> ((i2 - 1) & 63)) & 1) && !((occB[(j2 - 1) >> 6] >> ((j2 - 1) & 63)) & 1)) { amb = true; break; }
+            }
           }
+          if (amb) { ambiguous = true; break; }
+          if (lane == 0) {
+            conn[cnt * 2] = partA_off + wi * 3 + 2;
+            conn[cnt * 2 + 1] = partB_off + wj * 3 + 2;
+            cs[cnt] = sc;
+          }
+          cnt++;
+          occA[(wi - 1) >> 6] |= 1ull << ((wi - 1) & 63);
+          occB[(wj - 1) >> 6] |= 1ull << ((wj - 1) & 63);
+          done |= (2ull << first) - 1ull;  // rows up to and including `first` are decided
         }
-        if (amb) { ambiguous = true; break; }
-        if (lane == 0) {
-          conn[cnt * 2] = partA_off + wi * 3 + 2;
-          conn[cnt * 2 + 1] = partB_off + wj * 3 + 2;
-          cs[cnt] = sc;
-        }
-        cnt++;
-        occA[(wi - 1) >> 6] |= 1ull << ((wi - 1) & 63);
-        occB[(wj - 1) >> 6] |= 1ull << ((wj - 1) & 63);
-        done |= (2ull << first) - 1ull;  // rows up to and including `first` are decided
       }
     }
+    if (lane == 0) { if (ambiguous) flags |= 2; s_cnt = cnt; }
   }
-  if (ambiguous) {
-    if (lane == 0) {
+  __syncthreads();
+  if (flags) {  // exact path: the survivors again in loop order, then libstdc++'s introsort on lane 0
+    Cand* cands = (Cand*)lds_raw;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    compact([&](int ord, float sc, int ij) { cands[ord].score = sc; cands[ord].ij = ij; });
+    if (tid == 0) {
       std_sort_replica(cands, nc);
-      cnt = 0;
-      unsigned long long occA[4] = {0, 0, 0, 0}, occB[4] = {0, 0, 0, 0};
+      int cnt = 0;
+      unsigned long long occA[2] = {0, 0}, occB[2] = {0, 0};
       for (int row = 0; row < nc; ++row) {
         if (cnt == num) break;
         const Cand c = cands[row];
@@ -446,116 +499,131 @@ __global__ __launch_bounds__(256) void connect_score_kernel(ConnectParams p) {
           occB[(j - 1) >> 6] |= bb;
         }
       }
+      s_cnt = cnt;
     }
-    cnt = __shfl(cnt, 0);
   }
-  if (lane == 0) {
-    if (err) *p.num_people = CONNECT_ERR_RANGE;
-    p.cand_count[k] = nc | (ambiguous ? (1 << 30) : 0);  // bit 30: the exact-tie path ran (diagnostics only)
-    p.conn_count[k] = cnt;
+  if (tid == 0) {
+    p.cand_count[k] = nc | (flags ? (1 << 30) : 0);  // bit 30: the exact path ran (diagnostics only)
+    p.conn_count[k] = s_cnt;
   }
 }
 
-// Person assembly (rtpose.cpp:982-1046 / :684-722) + emission (:1051-1073 / :726-748).
-// ONE wavefront; the subset table lives in LDS: idx[max_rows][num_parts] (flat index of the
-// part's score in the peaks array, 0 = absent), score[max_rows] (double), cnt[max_rows].
-__global__ __launch_bounds__(64) void connect_assemble_kernel(ConnectParams p) {
+// Person assembly (rtpose.cpp:982-1046 / :684-722) + emission (:1051-1073 / :726-748), one workgroup.
+// The subset table lives in LDS: idx[max_rows][num_parts] (flat index of the part's score in the
+// peaks array, 0 = absent; int16), score[max_rows] (double), cnt[max_rows].
+// The reference walks connections in order and for each scans all rows for subset[j][partA] ==
+// indexA.  Within one limb every A peak belongs to at most one connection and only column partB is
+// written, so the scan can be turned inside out: ONE pass over the rows looks up the connection
+// owning the row's partA peak (conn_of[]), updates the row, and marks the connection as matched;
+// unmatched connections then append their rows in connection order, exactly as the serial loop.
+__global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int NP = p.num_parts;
   double* sscore = (double*)lds_raw;                       // [max_rows]
-  int* scnt = (int*)(sscore + p.max_rows);                 // [max_rows]
-  int* sidx = scnt + p.max_rows;                           // [max_rows][NP]
-  const int lane = threadIdx.x;
+  short* scnt = (short*)(sscore + p.max_rows);             // [max_rows]
+  short* sidx = scnt + p.max_rows;                         // [max_rows][NP]
+  __shared__ short conn_of[128];   // A-peak ordinal -> connection (or -1); single-sided: presence flag
+  __shared__ int matched[128];
+  __shared__ int wave_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool coco = p.model == 0;
   const int* limbSeq = coco ? kCocoLimb : kMpiLimb;
   const int peaks_offset = 3 * (p.max_peaks + 1);
   const float* peaks = p.peaks;
-  if (*p.num_people < 0) return;  // the score kernel flagged out-of-contract data
-  int nrows = 0;
+  if (*p.num_people < 0) return;  // the pair kernel flagged out-of-contract data
+  int nrows = 0;                  // uniform over the workgroup
 
-  auto append = [&](int partA, int idxA, int partB, int idxB, int cnt, double score) {
-    // all lanes call; lane 0 writes
-    if (nrows < p.max_rows) {
-      if (lane < NP) sidx[nrows * NP + lane] = 0;
-      __syncthreads();
-      if (lane == 0) {
-        sidx[nrows * NP + partA] = idxA;
-        if (partB >= 0) sidx[nrows * NP + partB] = idxB;
-        scnt[nrows] = cnt;
-        sscore[nrows] = score;
-      }
-      __syncthreads();
-      nrows++;
+  // rows for the items (tid < n) whose `want` is set, appended in item order
+  auto append_rows = [&](int n, bool want, int partA, int idxA, int partB, int idxB, int cnt, double score) {
+    const unsigned long long bal = __ballot(want && tid < n);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    const int row = nrows + before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (want && tid < n && row < p.max_rows) {
+      for (int q = 0; q < NP; ++q) sidx[row * NP + q] = 0;
+      sidx[row * NP + partA] = (short)idxA;
+      if (partB >= 0) sidx[row * NP + partB] = (short)idxB;
+      scnt[row] = (short)cnt;
+      sscore[row] = score;
     }
+    __syncthreads();
+    nrows = nrows + total < p.max_rows ? nrows + total : p.max_rows;
   };
 
   for (int k = 0; k < p.num_limbs; ++k) {
     const int partA = limbSeq[2 * k], partB = limbSeq[2 * k + 1];
-    const float* candA = peaks + partA * peaks_offset;
-    const float* candB = peaks + partB * peaks_offset;
-    int nA = (int)candA[0], nB = (int)candB[0];
-    if (nA > p.max_peaks) nA = p.max_peaks;
-    if (nB > p.max_peaks) nB = p.max_peaks;
+    const float *candA, *candB;
+    int nA, nB;
+    limb_setup(p, k, candA, candB, nA, nB);
     if (nA == 0 && nB == 0) continue;
     if (nA == 0 || nB == 0) {
       const int part = (nA == 0) ? partB : partA;
       const float* cand = (nA == 0) ? candB : candA;
       const int n = (nA == 0) ? nB : nA;
-      for (int i = 1; i <= n; ++i) {
-        const int off = part * peaks_offset + i * 3 + 2;
-        int found = 0;
-        if (coco) {  // rtpose.cpp:849-858, 873-881; the MPI version appends unconditionally
-          for (int j = lane; j < nrows; j += 64)
-            if (sidx[j * NP + part] == off) found = 1;
-          found = __any(found);
+      if (tid < 128) conn_of[tid] = 0;
+      __syncthreads();
+      if (coco) {  // rtpose.cpp:849-858, 873-881: only peaks no row holds yet; the MPI version appends unconditionally
+        for (int j = tid; j < nrows; j += 256) {
+          const int v = sidx[j * NP + part];
+          if (v) conn_of[(v - part * peaks_offset - 2) / 3] = 1;
         }
-        if (!found) append(part, off, -1, 0, 1, (double)cand[i * 3 + 2]);
+        __syncthreads();
       }
+      const int i = tid + 1;
+      const bool want = tid < n && !conn_of[i < 128 ? i : 0];
+      append_rows(n, want, part, part * peaks_offset + i * 3 + 2, -1, 0, 1, tid < n ? (double)cand[i * 3 + 2] : 0.0);
       continue;
     }
     const int nconn = p.conn_count[k];
     const int* conn = p.conn + (long)k * p.max_peaks * 2;
     const float* cs = p.conn_score + (long)k * p.max_peaks;
-    if (k == 0) {
-      for (int i = 0; i < nconn; ++i) {
-        const int indexA = conn[i * 2], indexB = conn[i * 2 + 1];
-        const double sc = (double)(peaks[indexA] + peaks[indexB]) + (double)cs[i];
-        append(partA, indexA, partB, indexB, 2, sc);
+    if (k != 0 && nconn == 0) continue;
+    int indexA = 0, indexB = 0;
+    float csv = 0.f;
+    if (tid < nconn) { indexA = conn[tid * 2]; indexB = conn[tid * 2 + 1]; csv = cs[tid]; }
+    if (k != 0) {
+      if (tid < 128) { conn_of[tid] = -1; matched[tid] = 0; }
+      __syncthreads();
+      if (tid < nconn) conn_of[(indexA - partA * peaks_offset - 2) / 3] = (short)tid;
+      __syncthreads();
+      for (int j = tid; j < nrows; j += 256) {
+        const int v = sidx[j * NP + partA];
+        if (!v) continue;
+        const int c = conn_of[(v - partA * peaks_offset - 2) / 3];
+        if (c < 0) continue;
+        const int iB = conn[c * 2 + 1];
+        sidx[j * NP + partB] = (short)iB;
+        scnt[j] = (short)(scnt[j] + 1);
+        sscore[j] = (sscore[j] + (double)peaks[iB]) + (double)cs[c];
+        matched[c] = 1;
       }
-    } else {
-      if (nconn == 0) continue;
-      for (int i = 0; i < nconn; ++i) {
-        const int indexA = conn[i * 2], indexB = conn[i * 2 + 1];
-        int num = 0;
-        for (int j = lane; j < nrows; j += 64) {
-          if (sidx[j * NP + partA] == indexA) {
-            sidx[j * NP + partB] = indexB;
-            num = 1;
-            scnt[j] = scnt[j] + 1;
-            sscore[j] = (sscore[j] + (double)peaks[indexB]) + (double)cs[i];
-          }
-        }
-        __syncthreads();
-        if (!__any(num)) {
-          const double sc = (double)(peaks[indexA] + peaks[indexB]) + (double)cs[i];
-          append(partA, indexA, partB, indexB, 2, sc);
-        }
-      }
+      __syncthreads();
     }
+    const bool want = tid < nconn && (k == 0 || !matched[tid]);
+    const double sc = tid < nconn ? (double)(peaks[indexA] + peaks[indexB]) + (double)csv : 0.0;
+    append_rows(nconn, want, partA, indexA, partB, indexB, 2, sc);
   }
   __syncthreads();
 
   // emit rows that pass the subset thresholds, in row order, at most max_people
   int out = 0;
-  for (int base = 0; base < nrows && out < p.max_people; base += 64) {
-    const int j = base + lane;
+  for (int base = 0; base < nrows && out < p.max_people; base += 256) {
+    const int j = base + tid;
     int ok = 0;
     if (j < nrows) {
       const double c = (double)scnt[j];
       ok = (c >= (double)p.min_subset_cnt) && ((sscore[j] / c) > (double)p.min_subset_score);
     }
     const unsigned long long bal = __ballot(ok);
-    const int slot = out + __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    const int slot = out + before + __popcll(bal & ((1ull << lane) - 1ull));
     if (ok && slot < p.max_people) {
       for (int q = 0; q < NP; ++q) {
         const int idx = sidx[j * NP + q];
@@ -569,28 +637,36 @@ __global__ __launch_bounds__(64) void connect_assemble_kernel(ConnectParams p) {
         }
       }
     }
-    out += __popcll(bal);
+    __syncthreads();
+    out += total;
   }
-  if (lane == 0) *p.num_people = out < p.max_people ? out : p.max_people;
+  if (tid == 0) *p.num_people = out < p.max_people ? out : p.max_people;
 }
 
 hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
-  const size_t lds1 = 2 * (size_t)p.max_peaks * p.max_peaks * sizeof(Cand);
-  static bool attr1 = false, attr2 = false;
-  const size_t lds2 = (size_t)p.max_rows * (sizeof(double) + sizeof(int) + sizeof(int) * p.num_parts);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  (void)attr1; (void)attr2;
-  e = hipFuncSetAttribute((const void*)connect_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)connect_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(connect_score_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
+  const int cap = p.max_peaks * p.max_peaks;
+  size_t n2 = 64;
+  while ((int)n2 < cap) n2 <<= 1;
+  const size_t lds1 = n2 * sizeof(unsigned long long);
+  const size_t lds2 = (size_t)p.max_rows * (sizeof(double) + sizeof(short) + sizeof(short) * p.num_parts);
+  if (p.max_peaks > 127) return hipErrorInvalidValue;
+  if (lds1 > 64 * 1024) {
+    e = hipFuncSetAttribute((const void*)connect_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return e;
+  }
+  if (lds2 > 64 * 1024) {
+    e = hipFuncSetAttribute((const void*)connect_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(connect_pairs_kernel, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(64), lds2, stream, p);
+  hipLaunchKernelGGL(connect_match_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(256), lds2, stream, p);
   return hipGetLastError();
 }
 

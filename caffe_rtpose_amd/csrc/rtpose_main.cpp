@@ -50,7 +50,7 @@ struct Flags {
   double start_scale = 1, scale_gap = 0.3;
   // extensions (not in the reference)
   std::string precision = "fp16", model = "";  // --model coco|mpi: use the built-in graph + synthetic weights
-  int frames_in_flight = 2;
+  int frames_in_flight = 2, batch_frames = 1;
   unsigned long long synthetic_seed = 1;
 };
 
@@ -59,7 +59,7 @@ int parse_flags(int argc, char** argv, Flags& F) {
       {"image_dir", &F.image_dir}, {"caffemodel", &F.caffemodel}, {"caffeproto", &F.caffeproto}, {"resolution", &F.resolution},
       {"net_resolution", &F.net_resolution}, {"camera_resolution", &F.camera_resolution}, {"precision", &F.precision}, {"model", &F.model}};
   std::map<std::string, int*> iflags = {{"part_to_show", &F.part_to_show}, {"camera", &F.camera}, {"start_frame", &F.start_frame},
-      {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}};
+      {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}, {"batch_frames", &F.batch_frames}};
   std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}};
   std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"host_preprocess", &F.host_preprocess}, {"no_display", &F.no_display},
       {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}};
@@ -100,7 +100,7 @@ void usage() {
          "  --caffeproto FILE --caffemodel FILE   | --model coco|mpi (built-in graph, synthetic weights)\n"
          "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
          "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
-         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K --host_preprocess]\n");
+         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K --batch_frames B --host_preprocess]\n");
 }
 
 // ---- queues (caffe::BlockingQueue, util/blocking_queue.cpp:26-61) -----------------------------
@@ -212,6 +212,7 @@ void worker(int device, int* status) {
   cfg.disp_w = DISP_W; cfg.disp_h = DISP_H;
   cfg.precision = F.precision == "fp32" ? RTP_PREC_FP32 : RTP_PREC_FP16;
   cfg.frames_in_flight = F.frames_in_flight;
+  cfg.batch_frames = F.batch_frames;
   rtp_engine* e = nullptr;
   if (rtp_engine_create(&cfg, &e) != RTP_OK) {
     fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));

@@ -244,6 +244,9 @@ class Engine:
                                            disp.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(fs)))
         return x, disp, fs.value
 
+    def flush(self):
+        self._chk(lib.rtp_flush(self.h))
+
     def collect(self):
         tag = C.c_uint64()
         n = C.c_int()

@@ -60,7 +60,13 @@ typedef struct rtp_config {
   float scale_gap;         /* --scale_gap   -> ImResizeLayer::SetScaleGap   (rtpose.cpp:202)       */
   int disp_w, disp_h;      /* --resolution: joints are returned in display coordinates (:1061)     */
   int precision;           /* RTP_PREC_*                                                            */
-  int frames_in_flight;    /* >=1: independent frame contexts (stream + activations) per engine    */
+  int frames_in_flight;    /* >=1: frames that may be submitted before a collect is needed         */
+  int batch_frames;        /* >=1: frames whose conv stacks share one launch sequence (0 = 1).     *
+                            * The reference runs one frame (num_scales images) per Forward; with   *
+                            * B > 1 the engine stages B submitted frames and runs the stack over   *
+                            * B*num_scales images (bigger tiles fill the 256 CUs), then post-      *
+                            * processes each frame on its own stream.  Per-frame results do not    *
+                            * depend on B.  ceil(frames_in_flight / B) batches are in flight.       */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
@@ -107,6 +113,10 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr_host, int w, int h,
 /* Parity tap for the device pre-processing alone. */
 int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr_host, int w, int h, float* net_input_host,
                          unsigned char* display_bgr_host, float* frame_scale);
+
+/* Launch a partially filled batch now (batch_frames > 1: end of stream or a latency-sensitive
+ * caller).  rtp_collect does this by itself when the oldest frame sits in an unlaunched batch. */
+int rtp_flush(rtp_engine* e);
 
 /* Blocks until the OLDEST submitted frame is finished; returns its tag, the number of people
  * (<= RTP_MAX_PEOPLE) and joints[num_people][num_parts][3] = (x, y, score) in display

@@ -387,3 +387,43 @@ def test_submit_frame_enlarging_level_falls_back_to_host_restatement():
     with pytest.raises(r.RtpError):
         e.debug_preprocess(img)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------
+# frame batching: B frames share one conv launch sequence; per-frame results do not depend on B
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec_name,B,N", [("fp16", 3, 1), ("fp32", 2, 2)])
+def test_frame_batching_is_transparent(prec_name, B, N):
+    import caffe_rtpose_amd as r
+    prec = r.PREC_FP16 if prec_name == "fp16" else r.PREC_FP32
+    W, H = 320, 176
+    e = _engine(net_w=W, net_h=H, num_scales=N, scale_gap=0.25, disp_w=640, disp_h=360, frames_in_flight=2 * B, batch_frames=B, precision=prec)
+    imgs = [r.synth_frame(640, 360, i, seed=21) for i in range(2 * B + 2)]   # 2 full batches + a partial one
+    xs = [r.preprocess_frame(im, 640, 360, W, H, N, 1.0, 0.25)[0] for im in imgs]
+    want = [e.forward_debug(x) for x in xs]                                   # one frame alone (slot 0, nimg = N)
+    assert sum(d["num_people"] for d in want) > 0
+    # the fp32 plan against the oracle's conv stack (the batch plan picks other tiles than B = 1)
+    if prec_name == "fp32":
+        net = _oracle_net_from(e)
+        net.forward(xs[0], keep_all=True)
+        assert _rel_err(e.forward_heatmaps(xs[0]), net.blob("concat_stage7")) < 2e-4
+    got = []
+    for i, x in enumerate(xs):           # mixed entry points, FIFO order, partial batch launched by collect
+        if i % 2 == 0:
+            e.submit(x, tag=i)
+        else:
+            e.submit_frame(imgs[i], tag=i)
+        while e.in_flight() >= 2 * B:
+            got.append(e.collect())
+    while e.in_flight():
+        got.append(e.collect())
+    assert [g[0] for g in got] == list(range(len(xs)))
+    for (tag, n, joints), d in zip(got, want):
+        assert n == d["num_people"]
+        assert np.array_equal(joints, d["joints"][:n])
+    # flush: a lone frame in an open batch runs without waiting for the batch to fill
+    e.submit(xs[0], tag=77)
+    e.flush()
+    tag, n, joints = e.collect()
+    assert tag == 77 and n == want[0]["num_people"] and np.array_equal(joints, want[0]["joints"][:n])
+    e.close()
