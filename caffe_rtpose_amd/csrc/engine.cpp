@@ -1119,6 +1119,7 @@ int rtp_flush(rtp_engine* e) {
   return launch_open(e);
 }
 
+static int need_idle(rtp_engine* e);
 // Parity tap: the device pre-processing alone (net input and display image back on the host).
 int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, float* net_input, unsigned char* display_bgr, float* frame_scale) {
   int rc;
