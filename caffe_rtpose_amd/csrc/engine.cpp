@@ -1556,6 +1556,51 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
   return RTP_OK;
 }
 
+// Diagnostics: every step of the plan alone on the chip, `iters` back-to-back launches at the full
+// batch; ms[i] = average launch time of step i, gflop[i] = its convolution work (0 for pack/pool).
+int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int cap) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (iters < 1) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  auto geom_n = [&](int level) { Geom g = e->geom[level]; g.N = e->NI; return g; };
+  int n = 0;
+  for (auto& s : e->steps) {
+    if (n >= cap) break;
+    auto once = [&]() -> int {
+      if (s.type == 0) {
+        const Tensor& t = e->tensors[0];
+        HIPCHK(e, launch_pack_input(e->prec, cx.input, cx.arena + t.offset, geom_n(0), t.Cp, cx.stream));
+      } else if (s.type == 1) {
+        return launch_conv_step(e, cx, s, e->NI);
+      } else {
+        const PoolOp& p = e->pools[s.a];
+        const Tensor& ti = e->tensors[p.in_tensor];
+        const Tensor& to = e->tensors[p.out_tensor];
+        HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.Cp, cx.arena + to.offset, geom_n(to.level), to.Cp,
+                                 round_up(p.C, 16 / e->elem), cx.stream));
+      }
+      return RTP_OK;
+    };
+    for (int i = 0; i < 2; ++i) if ((rc = once())) return rc;
+    HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
+    for (int i = 0; i < iters; ++i) if ((rc = once())) return rc;
+    HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
+    HIPCHK(e, hipEventSynchronize(cx.ev[1]));
+    float t = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&t, cx.ev[0], cx.ev[1]));
+    if (ms) ms[n] = t / iters;
+    double fl = 0;
+    if (s.type == 1) {
+      const Geom& g = e->geom[e->convs[s.a].level];
+      for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->NI; }
+    }
+    if (gflop) gflop[n] = fl * 1e-9;
+    ++n;
+  }
+  return n;
+}
+
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch) {
   int rc;
   if ((rc = need_idle(e))) return rc;

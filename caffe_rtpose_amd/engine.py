@@ -244,6 +244,14 @@ class Engine:
                                            disp.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(fs)))
         return x, disp, fs.value
 
+    def profile_steps(self, iters=20):
+        ms = (C.c_float * 256)()
+        gf = (C.c_double * 256)()
+        n = lib.rtp_profile_steps(self.h, iters, ms, gf, 256)
+        if n < 0:
+            self._chk(n)
+        return list(ms)[:n], list(gf)[:n]
+
     def flush(self):
         self._chk(lib.rtp_flush(self.h))
 

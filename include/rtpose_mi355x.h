@@ -199,6 +199,10 @@ const char* rtp_version(void);
 /* Per-stage device time of the last collected frame, ms: [0]=conv stack [1]=resize [2]=nms
  * [3]=connect [4]=total (the reference's "CNN time / Connect time" VLOGs, rtpose.cpp:1147,1168). */
 int rtp_last_stage_ms(const rtp_engine* e, float ms[5]);
+/* Diagnostics: each plan step alone on the chip (back-to-back launches at the full batch).
+ * Returns the number of steps written (same order as rtp_plan_summary's "step" lines). */
+int rtp_profile_steps(rtp_engine* e, int iters, float* ms_per_step, double* gflop_per_step, int cap);
+
 /* Time `iters` launches of the dominant conv kernel (Mconv 7x7 128->128 pair of stage 2) with
  * HIP events on the engine's stream; returns avg ms per launch and the algorithmic FLOPs of one
  * launch.  Used by bench.py for the roofline line. */
