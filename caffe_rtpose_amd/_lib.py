@@ -52,6 +52,7 @@ SIGNATURES = {
     "rtp_submit_frame": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint64, fp]),
     "rtp_debug_preprocess": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, fp, C.POINTER(C.c_ubyte), fp]),
     "rtp_flush": (C.c_int, [vp]),
+    "rtp_post_from_lowres": (C.c_int, [vp, fp, fp, fp, ip]),
     "rtp_profile_steps": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_double), C.c_int]),
     "rtp_collect": (C.c_int, [vp, C.POINTER(C.c_uint64), fp, ip]),
     "rtp_in_flight": (C.c_int, [vp]),

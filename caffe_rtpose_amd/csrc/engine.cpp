@@ -639,26 +639,32 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg) {
   return RTP_OK;
 }
 
-int run_resize(rtp_engine* e, Ctx& cx, int sj = 0) {
+ResizeParams resize_params(rtp_engine* e, Ctx& cx, int sj) {
   Slot& sl = cx.slot[sj];
   ResizeParams rp;
   rp.src = cx.lowres + (size_t)sj * e->N * e->heat_channels * e->low_h * e->low_w;
   rp.dst = sl.resized; rp.num = e->N; rp.C = e->heat_channels;
   rp.h = e->low_h; rp.w = e->low_w; rp.tw = e->cfg.net_w; rp.th = e->cfg.net_h;
   rp.start_scale = e->start_scale; rp.scale_gap = e->scale_gap;
-  HIPCHK(e, launch_resize(rp, sl.stream));
+  return rp;
+}
+int run_resize(rtp_engine* e, Ctx& cx, int sj = 0) {
+  HIPCHK(e, launch_resize(resize_params(e, cx, sj), cx.slot[sj].stream));
   return RTP_OK;
 }
-int run_nms(rtp_engine* e, Ctx& cx, int sj = 0) {
+NmsParams nms_params(rtp_engine* e, Ctx& cx, int sj) {
   Slot& sl = cx.slot[sj];
   NmsParams np;
   np.src = sl.resized; np.peaks = sl.peaks; np.strip_count = sl.strip_count; np.strip_list = sl.strip_list;
   np.src_planes = e->heat_channels; np.H = e->cfg.net_h; np.W = e->cfg.net_w; np.num_parts = e->num_parts;
   np.max_peaks = e->max_peaks; np.nstrips = e->nstrips; np.strip_rows = e->strip_rows; np.threshold = e->nms_threshold;
-  HIPCHK(e, launch_nms(np, sl.stream));
+  return np;
+}
+int run_nms(rtp_engine* e, Ctx& cx, int sj = 0) {
+  HIPCHK(e, launch_nms(nms_params(e, cx, sj), cx.slot[sj].stream));
   return RTP_OK;
 }
-int run_connect(rtp_engine* e, Ctx& cx, int sj = 0) {
+ConnectParams connect_params(rtp_engine* e, Ctx& cx, int sj) {
   Slot& sl = cx.slot[sj];
   ConnectParams cp;
   memset(&cp, 0, sizeof cp);
@@ -669,13 +675,26 @@ int run_connect(rtp_engine* e, Ctx& cx, int sj = 0) {
   cp.max_peaks = e->max_peaks; cp.net_w = e->cfg.net_w; cp.net_h = e->cfg.net_h; cp.disp_w = e->cfg.disp_w; cp.disp_h = e->cfg.disp_h;
   cp.inter_threshold = e->inter_threshold; cp.inter_min_above = e->inter_min_above; cp.min_subset_cnt = e->min_subset_cnt;
   cp.min_subset_score = e->min_subset_score; cp.max_people = RTP_MAX_PEOPLE;
-  HIPCHK(e, launch_connect(cp, sl.stream));
+  return cp;
+}
+int run_connect(rtp_engine* e, Ctx& cx, int sj = 0) {
+  HIPCHK(e, launch_connect(connect_params(e, cx, sj), cx.slot[sj].stream));
+  return RTP_OK;
+}
+// production post-processing: peaks and PAF samples straight from the low-res maps; the 55 MB
+// resized map is never written (the taps / rtp_forward_debug still materialise it)
+int run_post_fused(rtp_engine* e, Ctx& cx, int sj, hipEvent_t ev_nms) {
+  Slot& sl = cx.slot[sj];
+  const ResizeParams rp = resize_params(e, cx, sj);
+  HIPCHK(e, launch_nms_fused(nms_params(e, cx, sj), rp, sl.stream));
+  HIPCHK(e, hipEventRecord(ev_nms, sl.stream));
+  HIPCHK(e, launch_connect_fused(connect_params(e, cx, sj), rp, sl.stream));
   return RTP_OK;
 }
 
 // one batch on one context: conv stack over nframes*num_scales images, then per frame (on the
 // frame slot's stream) resize -> nms -> connect -> D2H of the joints
-int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev) {
+int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize = false) {
   int rc;
   HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
   if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N))) return rc;
@@ -686,12 +705,18 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev) {
     if (sl.stream != cx.stream) HIPCHK(e, hipStreamWaitEvent(sl.stream, cx.ev[1], 0));
     static const char* diag = getenv("RTP_DIAG_SKIP_POST");  // diagnosis only: 1 = no connect, 2 = no post-processing at all
     const int skip = diag ? atoi(diag) : 0;
+    static const char* unf = getenv("RTP_POST_UNFUSED");  // experiments: production path through the materialised map
     HIPCHK(e, hipEventRecord(sl.ev[0], sl.stream));
-    if (skip < 2 && (rc = run_resize(e, cx, j))) return rc;
-    HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
-    if (skip < 2 && (rc = run_nms(e, cx, j))) return rc;
-    HIPCHK(e, hipEventRecord(sl.ev[2], sl.stream));
-    if (skip < 1 && (rc = run_connect(e, cx, j))) return rc;
+    if (materialize || skip || (unf && unf[0] == '1')) {
+      if (skip < 2 && (rc = run_resize(e, cx, j))) return rc;
+      HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
+      if (skip < 2 && (rc = run_nms(e, cx, j))) return rc;
+      HIPCHK(e, hipEventRecord(sl.ev[2], sl.stream));
+      if (skip < 1 && (rc = run_connect(e, cx, j))) return rc;
+    } else {
+      HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));  // no resize stage
+      if ((rc = run_post_fused(e, cx, j, sl.ev[2]))) return rc;
+    }
     HIPCHK(e, hipEventRecord(sl.ev[3], sl.stream));
     HIPCHK(e, hipMemcpyAsync(sl.host_out + 4, sl.joints, jbytes, hipMemcpyDeviceToHost, sl.stream));
     HIPCHK(e, hipMemcpyAsync(sl.host_out, sl.num_people, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
@@ -700,7 +725,7 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev) {
   cx.launched = true;
   return RTP_OK;
 }
-int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev) { return launch_batch(e, cx, 1, input_dev); }
+int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev, bool materialize = false) { return launch_batch(e, cx, 1, input_dev, materialize); }
 
 int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   if (share_stream) sl.stream = cx.stream;
@@ -1195,7 +1220,7 @@ int rtp_forward_debug(rtp_engine* e, const float* h_in, float* lowres, float* re
   Ctx& cx = e->ctx[0];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   HIPCHK(e, hipMemcpy(cx.input, h_in, bytes, hipMemcpyHostToDevice));
-  if ((rc = enqueue_frame(e, cx, cx.input))) return rc;
+  if ((rc = enqueue_frame(e, cx, cx.input, true))) return rc;  // taps: materialised map
   HIPCHK(e, hipStreamSynchronize(cx.stream));
   if (lowres) HIPCHK(e, hipMemcpy(lowres, cx.lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyDeviceToHost));
   Slot& sl = cx.slot[0];
@@ -1233,6 +1258,27 @@ int rtp_resize(rtp_engine* e, const float* lowres, float* resized) {
   if ((rc = run_resize(e, cx))) return rc;
   HIPCHK(e, hipStreamSynchronize(cx.stream));
   HIPCHK(e, hipMemcpy(resized, cx.slot[0].resized, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
+// Parity tap for the PRODUCTION post-processing (no resized map): low-res maps in, peaks and joints out.
+int rtp_post_from_lowres(rtp_engine* e, const float* lowres, float* peaks, float* joints, int* num_people) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!lowres) return RTP_EINVAL;
+  Ctx& cx = e->ctx[0];
+  Slot& sl = cx.slot[0];
+  const size_t pbytes = (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float);
+  HIPCHK(e, hipMemcpy(cx.lowres, lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyHostToDevice));
+  if (peaks) HIPCHK(e, hipMemcpy(sl.peaks, peaks, pbytes, hipMemcpyHostToDevice));  // stale slots stay, like the reference's blob
+  if ((rc = run_post_fused(e, cx, 0, sl.ev[2]))) return rc;
+  HIPCHK(e, hipStreamSynchronize(sl.stream));
+  if (peaks) HIPCHK(e, hipMemcpy(peaks, sl.peaks, pbytes, hipMemcpyDeviceToHost));
+  int n = 0;
+  HIPCHK(e, hipMemcpy(&n, sl.num_people, sizeof(int), hipMemcpyDeviceToHost));
+  if (n < 0) { if (num_people) *num_people = 0; return fail(e, RTP_ERANGE, "connect: PAF sample coordinate out of range"); }
+  if (num_people) *num_people = n;
+  if (joints && n > 0) HIPCHK(e, hipMemcpy(joints, sl.joints, (size_t)n * e->num_parts * 3 * sizeof(float), hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 

@@ -124,6 +124,10 @@ struct NmsParams {
   float threshold;
 };
 hipError_t launch_nms(const NmsParams& p, hipStream_t stream);
+// Production path: the same peaks WITHOUT materialising the resized map — each strip workgroup
+// evaluates ImResize for its rows (+1 halo row) in LDS, the centroid windows are evaluated on demand.
+// `p.src` is ignored; `r.dst` is ignored.
+hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream);
 
 struct ConnectParams {
   const float* heat;   // resized map [C][net_h][net_w]
@@ -151,5 +155,7 @@ struct ConnectParams {
   int max_people;
 };
 hipError_t launch_connect(const ConnectParams& p, hipStream_t stream);
+// Production path: PAF samples are evaluated from the low-res maps on demand (`p.heat` ignored).
+hipError_t launch_connect_fused(const ConnectParams& p, const ResizeParams& r, hipStream_t stream);
 
 }  // namespace rtp

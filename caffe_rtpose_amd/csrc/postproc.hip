@@ -24,6 +24,18 @@
 #include "kernels.h"
 #include "stdsort_replica.h"
 
+// No packed-f32 VALU (v_pk_add/mul/fma_f32) in these kernels.  hipcc's SLP vectoriser pairs the x/y
+// halves of the scalar float math below into packed ops; with that, nms_fused_write_kernel returned
+// run-to-run different bits for the SAME inputs (whole 16-lane groups, inside divergent code) whenever
+// MFMA-heavy convolution workgroups of another frame shared its CU, and never on an idle chip
+// (tools/race_probe_post.py; in-kernel re-evaluation self-check).  Scalar f32 ops are bit-identical
+// by definition, and with them 0 mismatches in the same stress.  Cost: nothing measurable.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RTP_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define RTP_NO_PK_F32
+#endif
+
 namespace rtp {
 
 // ---------------------------------------------------------------------------------------
@@ -37,13 +49,68 @@ __device__ __forceinline__ float cubic_interp(float v0, float v1, float v2, floa
   return (float)((((double)t1 + t2) + (double)t3) + (double)v1);
 }
 
+// Geometry of scale n (imresize_layer.cu:99-131)
+struct ScaleGeo {
+  int padw, padh, ow, oh, rw;
+  float offset_x, offset_y, fx, fy;  // fx = (float)ow / tw
+};
+__device__ __forceinline__ ScaleGeo scale_geo(const ResizeParams& p, int n) {
+  ScaleGeo g;
+  g.padw = (int)floorf((float)(p.w / 2) * (1 - p.start_scale + n * p.scale_gap));
+  g.padh = (int)floorf((float)(p.h / 2) * (1 - p.start_scale + n * p.scale_gap));
+  g.ow = p.w - 2 * g.padw;
+  g.oh = p.h - 2 * g.padh;
+  g.offset_x = (float)((double)(p.tw / (float)g.ow / 2) - 0.5);
+  g.offset_y = (float)((double)(p.th / (float)g.oh / 2) - 0.5);
+  g.rw = g.ow + 2 * g.padw;
+  g.fx = (float)g.ow / p.tw;
+  g.fy = (float)g.oh / p.th;
+  return g;
+}
+// neighbour indices (already padded) and fraction along one axis
+__device__ __forceinline__ float axis_nb(int x, float offset, float f, int osize, int pad, int nb[4]) {
+  const float x_on = (x - offset) * f;
+  int xn1 = (int)((double)x_on + 1e-5);
+  xn1 = (xn1 < 0) ? 0 : xn1;
+  const float dx = x_on - xn1;
+  nb[0] = ((xn1 - 1 < 0) ? xn1 : (xn1 - 1)) + pad;
+  const int xn2 = (xn1 + 1 >= osize) ? (osize - 1) : (xn1 + 1);
+  nb[3] = ((xn2 + 1 >= osize) ? (osize - 1) : (xn2 + 1)) + pad;
+  nb[1] = xn1 + pad;
+  nb[2] = xn2 + pad;
+  return dx;
+}
+// ONE output of the resized map, computed exactly as resize_kernel computes it (same operations in
+// the same order per scale, same accumulation over scales).
+__device__ __forceinline__ float resized_at(const ResizeParams& p, int c, int y, int x) {
+  const long plane = (long)p.h * p.w;
+  const float* src_c = p.src + (long)c * plane;
+  float sum = 0.f;
+  for (int n = 0; n < p.num; ++n) {
+    const ScaleGeo g = scale_geo(p, n);
+    const float* sp = src_c + (long)n * p.C * plane;
+    int xn[4], yn[4];
+    const float dx = axis_nb(x, g.offset_x, g.fx, g.ow, g.padw, xn);
+    const float dy = axis_nb(y, g.offset_y, g.fy, g.oh, g.padh, yn);
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* rr = sp + yn[i] * g.rw;
+      t[i] = cubic_interp(rr[xn[0]], rr[xn[1]], rr[xn[2]], rr[xn[3]], dx);
+    }
+    const float d = cubic_interp(t[0], t[1], t[2], t[3], dy);
+    sum = sum + d;
+  }
+  return sum / p.num;
+}
+
 // One thread = an 8x8 block of outputs of one channel: x0 = 8k-4, y0 = 8m-4.  For the full-size
 // scale such a block shares ONE 4x4 low-res neighbourhood, so the 4 row interpolations t[i] of an
 // output column are computed once and reused by the 8 output rows (1.5 cubic evaluations per output
 // instead of 5) and the 16 neighbours are loaded once per block.  Per-output arithmetic and
 // rounding are exactly the reference kernel's; whenever the neighbourhood of an output differs
 // from the previous one (other scales, borders) it is simply recomputed.
-__global__ __launch_bounds__(128) void resize_kernel(ResizeParams p) {
+__global__ RTP_NO_PK_F32 __launch_bounds__(128) void resize_kernel(ResizeParams p) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;  // 8-wide column strip
   const int x0 = 8 * k - 4;
   const int y0 = 8 * (int)blockIdx.y - 4;
@@ -157,7 +224,7 @@ __device__ __forceinline__ int nms_flag(const float* s, int x, int y, int W, int
   return 0;
 }
 
-__global__ __launch_bounds__(256) void nms_strip_kernel(NmsParams p) {
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_strip_kernel(NmsParams p) {
   __shared__ int wave_cnt[4];
   __shared__ int running;
   const int strip = blockIdx.x, part = blockIdx.y;
@@ -191,7 +258,7 @@ __global__ __launch_bounds__(256) void nms_strip_kernel(NmsParams p) {
   if (tid == 0) p.strip_count[part * p.nstrips + strip] = running;
 }
 
-__global__ __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
   extern __shared__ int prefix[];  // [nstrips+1]
   const int part = blockIdx.x;
   const int tid = threadIdx.x;
@@ -242,6 +309,185 @@ __global__ __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
   if (tid == 0) dst[0] = (float)total;  // unclamped total, nms_layer.cu:110
 }
 
+// ---- map-free NMS -----------------------------------------------------------------------------
+// Strip kernel: resized rows y0-1 .. y1 of one part are built in LDS (row interpolations T of the
+// low-res rows the strip touches, then the column interpolation, accumulated over the scales in
+// scale order — the arithmetic of resize_kernel), then flagged exactly like nms_strip_kernel.
+#define NMSF_TROWS 8
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, ResizeParams r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int W = p.W, H = p.H;
+  float* out = (float*)lds_raw;                 // [strip_rows + 2][W]
+  float* T = out + (p.strip_rows + 2) * W;      // [NMSF_TROWS][W]
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int strip = blockIdx.x, part = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int y0 = strip * p.strip_rows;
+  const int y1 = min(y0 + p.strip_rows, H);
+  const int ya = max(y0 - 1, 0), yb = min(y1, H - 1);  // rows held in LDS: ya..yb
+  const int nrow = yb - ya + 1;
+  const long plane = (long)r.h * r.w;
+  for (int i = tid; i < nrow * W; i += 256) out[i] = 0.f;
+  if (tid == 0) running = 0;
+  __syncthreads();
+  for (int n = 0; n < r.num; ++n) {
+    const ScaleGeo g = scale_geo(r, n);
+    const float* sp = r.src + ((long)n * r.C + part) * plane;
+    int nb[4];
+    (void)axis_nb(ya, g.offset_y, g.fy, g.oh, g.padh, nb);
+    const int rlo = nb[0];
+    (void)axis_nb(yb, g.offset_y, g.fy, g.oh, g.padh, nb);
+    const int rhi = nb[3];
+    const int nt = rhi - rlo + 1;
+    if (nt <= NMSF_TROWS) {
+      for (int i = tid; i < nt * W; i += 256) {
+        const int rr = i / W, x = i - rr * W;
+        int xn[4];
+        const float dx = axis_nb(x, g.offset_x, g.fx, g.ow, g.padw, xn);
+        const float* row = sp + (rlo + rr) * g.rw;
+        T[rr * W + x] = cubic_interp(row[xn[0]], row[xn[1]], row[xn[2]], row[xn[3]], dx);
+      }
+      __syncthreads();
+      for (int i = tid; i < nrow * W; i += 256) {
+        const int yy = i / W, x = i - yy * W;
+        int yn[4];
+        const float dy = axis_nb(ya + yy, g.offset_y, g.fy, g.oh, g.padh, yn);
+        const float d = cubic_interp(T[(yn[0] - rlo) * W + x], T[(yn[1] - rlo) * W + x], T[(yn[2] - rlo) * W + x], T[(yn[3] - rlo) * W + x], dy);
+        out[i] = out[i] + d;
+      }
+      __syncthreads();
+    } else {  // a strip spanning more low-res rows than the table holds (not with net/8 maps): per pixel
+      for (int i = tid; i < nrow * W; i += 256) {
+        const int yy = i / W, x = i - yy * W;
+        int xn[4], yn[4];
+        const float dx = axis_nb(x, g.offset_x, g.fx, g.ow, g.padw, xn);
+        const float dy = axis_nb(ya + yy, g.offset_y, g.fy, g.oh, g.padh, yn);
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* row = sp + yn[q] * g.rw;
+          t[q] = cubic_interp(row[xn[0]], row[xn[1]], row[xn[2]], row[xn[3]], dx);
+        }
+        out[i] = out[i] + cubic_interp(t[0], t[1], t[2], t[3], dy);
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < nrow * W; i += 256) out[i] = out[i] / r.num;
+  __syncthreads();
+  const int npix = (y1 - y0) * W;
+  const int pix0 = y0 * W;
+  int* list = p.strip_list + ((long)part * p.nstrips + strip) * p.max_peaks;
+  const float* s = out - (long)ya * W;  // s[y * W + x] for y in ya..yb
+  for (int base = 0; base < npix; base += 256) {
+    const int q = base + tid;
+    int f = 0;
+    if (q < npix) {
+      const int gq = pix0 + q;
+      f = nms_flag(s, gq % W, gq / W, W, H, p.threshold);
+    }
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = running;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (f && ord < p.max_peaks) list[ord] = pix0 + q;
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) p.strip_count[part * p.nstrips + strip] = running;
+}
+
+// Write kernel: the 49 window values of every kept peak are evaluated on demand by all threads,
+// then one thread per peak accumulates them in the reference's (dy, dx) order.
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, ResizeParams r) {
+  extern __shared__ int dyn_i[];
+  int* prefix = dyn_i;                                   // [nstrips+1]
+  float* win = (float*)(dyn_i + p.nstrips + 1);          // [max_peaks][50]: 49 window values + centre
+  int* pix = (int*)(win + p.max_peaks * 50);             // [max_peaks]
+  const int part = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < p.nstrips; ++i) {
+      prefix[i] = run;
+      run += p.strip_count[part * p.nstrips + i];
+    }
+    prefix[p.nstrips] = run;
+  }
+  __syncthreads();
+  const int total = prefix[p.nstrips];
+  const int W = p.W, H = p.H;
+  float* dst = p.peaks + (long)part * (p.max_peaks + 1) * 3;
+  const int n = total < p.max_peaks ? total : p.max_peaks;
+  for (int e = tid; e < n; e += 256) {
+    int st = 0;
+    while (prefix[st + 1] <= e) ++st;  // strip holding ordinal e
+    pix[e] = p.strip_list[((long)part * p.nstrips + st) * p.max_peaks + (e - prefix[st])];
+  }
+  __syncthreads();
+  for (int it = tid; it < n * 50; it += 256) {
+    const int e = it / 50, wq = it - e * 50;
+    const int px = pix[e] % W, py = pix[e] / W;
+    float score = 0.f;
+    if (wq == 49) score = resized_at(r, part, py, px);
+    else {
+      const int dy = wq / 7 - 3, dx = wq % 7 - 3;
+      // writeResultKernel, nms_layer.cu:70-105: the bound on y is `width`, so the window may run
+      // past the last row of this part into the first rows of the next plane (or past the map: 0)
+      if ((py + dy) > 0 && (py + dy) < W && (px + dx) > 0 && (px + dx) < W) {
+        const int row = py + dy;
+        const int pl = part + row / H;
+        if (pl < p.src_planes) score = resized_at(r, pl, row % H, px + dx);
+      }
+    }
+    win[it] = score;
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const int px = pix[e] % W, py = pix[e] / W;
+    float x_acc = 0.f, y_acc = 0.f, score_acc = 0.f;
+    for (int dy = -3; dy < 4; ++dy) {
+      if ((py + dy) > 0 && (py + dy) < W) {
+        for (int dx = -3; dx < 4; ++dx) {
+          if ((px + dx) > 0 && (px + dx) < W) {
+            const float score = win[e * 50 + (dy + 3) * 7 + dx + 3];
+            const float fx = (float)(px + dx), fy = (float)(py + dy);
+            if (score > 0) {
+              x_acc += fx * score;
+              y_acc += fy * score;
+              score_acc += score;
+            }
+          }
+        }
+      }
+    }
+    const int oi = (e + 1) * 3;
+    dst[oi] = x_acc / score_acc;
+    dst[oi + 1] = y_acc / score_acc;
+    dst[oi + 2] = win[e * 50 + 49];
+  }
+  if (tid == 0) dst[0] = (float)total;  // unclamped total, nms_layer.cu:110
+}
+
+hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream) {
+  const size_t lds1 = (size_t)(p.strip_rows + 2 + NMSF_TROWS) * p.W * sizeof(float);
+  if (lds1 > 150 * 1024) return hipErrorInvalidValue;
+  if (lds1 > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)nms_fused_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(nms_fused_strip_kernel, dim3(p.nstrips, p.num_parts), dim3(256), lds1, stream, p, r);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const size_t lds2 = (p.nstrips + 1) * sizeof(int) + (size_t)p.max_peaks * 51 * sizeof(float);
+  hipLaunchKernelGGL(nms_fused_write_kernel, dim3(p.num_parts), dim3(256), lds2, stream, p, r);
+  return hipGetLastError();
+}
+
 hipError_t launch_nms(const NmsParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(nms_strip_kernel, dim3(p.nstrips, p.num_parts), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
@@ -285,7 +531,8 @@ __device__ __forceinline__ void limb_setup(const ConnectParams& p, int k, const 
   if (nB > p.max_peaks) nB = p.max_peaks;
 }
 
-__global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p) {
+template <bool FUSED>
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, ResizeParams r) {
   const int k = blockIdx.y;
   const int cap = p.max_peaks * p.max_peaks;
   const bool coco = p.model == 0;
@@ -327,7 +574,16 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p) {
     }
     float px[10], py[10];
 #pragma unroll
-    for (int lm = 0; lm < num_inter; lm++) { px[lm] = map_x[idxs[lm]]; py[lm] = map_y[idxs[lm]]; }
+    for (int lm = 0; lm < num_inter; lm++) {
+      if (FUSED) {  // the two PAF samples straight from the low-res maps (no resized map in memory)
+        const int my = idxs[lm] / NW, mx = idxs[lm] - my * NW;
+        px[lm] = resized_at(r, mapIdx[2 * k], my, mx);
+        py[lm] = resized_at(r, mapIdx[2 * k + 1], my, mx);
+      } else {
+        px[lm] = map_x[idxs[lm]];
+        py[lm] = map_y[idxs[lm]];
+      }
+    }
     float sum = 0;
     int count = 0;
 #pragma unroll
@@ -360,7 +616,7 @@ __device__ __forceinline__ float key_score(unsigned long long key) {
   return __uint_as_float(u);
 }
 
-__global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned long long* keys = (unsigned long long*)lds_raw;  // [pow2 >= survivors]
   __shared__ int wave_cnt[4];
@@ -516,7 +772,7 @@ __global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
 // written, so the scan can be turned inside out: ONE pass over the rows looks up the connection
 // owning the row's partA peak (conn_of[]), updates the row, and marks the connection as matched;
 // unmatched connections then append their rows in connection order, exactly as the serial loop.
-__global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
+__global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int NP = p.num_parts;
   double* sscore = (double*)lds_raw;                       // [max_rows]
@@ -643,7 +899,7 @@ __global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) 
   if (tid == 0) *p.num_people = out < p.max_people ? out : p.max_people;
 }
 
-hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) {
+static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams* r, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   const int cap = p.max_peaks * p.max_peaks;
@@ -660,7 +916,8 @@ hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) {
     e = hipFuncSetAttribute((const void*)connect_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(connect_pairs_kernel, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p);
+  if (r) hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p, *r);
+  else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p, ResizeParams{});
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(connect_match_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
@@ -669,5 +926,8 @@ hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(256), lds2, stream, p);
   return hipGetLastError();
 }
+
+hipError_t launch_connect(const ConnectParams& p, hipStream_t stream) { return launch_connect_impl(p, nullptr, stream); }
+hipError_t launch_connect_fused(const ConnectParams& p, const ResizeParams& r, hipStream_t stream) { return launch_connect_impl(p, &r, stream); }
 
 }  // namespace rtp

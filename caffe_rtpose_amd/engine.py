@@ -252,6 +252,14 @@ class Engine:
             self._chk(n)
         return list(ms)[:n], list(gf)[:n]
 
+    def post_from_lowres(self, lowres, peaks_in=None):
+        lowres = np.ascontiguousarray(lowres, np.float32)
+        peaks = np.zeros((self.num_parts, self.max_peaks + 1, 3), np.float32) if peaks_in is None else np.ascontiguousarray(peaks_in, np.float32).copy()
+        joints = np.zeros((MAX_PEOPLE, self.num_parts, 3), np.float32)
+        n = C.c_int()
+        self._chk(lib.rtp_post_from_lowres(self.h, _f(lowres), _f(peaks), _f(joints), C.byref(n)))
+        return peaks, joints[: n.value].copy(), n.value
+
     def flush(self):
         self._chk(lib.rtp_flush(self.h))
 

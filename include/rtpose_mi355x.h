@@ -133,6 +133,13 @@ int rtp_in_flight(const rtp_engine* e);
 int rtp_forward_heatmaps(rtp_engine* e, const float* nchw_input_host, float* lowres_host);
 /* ImResizeLayer::Forward_gpu on caller data: lowres (num_scales x C x h x w) -> resized (C x net_h x net_w). */
 int rtp_resize(rtp_engine* e, const float* lowres_host, float* resized_host);
+/* The PRODUCTION post-processing as a parity tap: rtp_submit/rtp_collect never materialise the
+ * 55 MB resized map — NMS builds the resized rows of each 8-row strip in LDS and the PAF samples /
+ * centroid windows are evaluated from the low-res maps on demand, with the arithmetic of
+ * imresize_layer.cu, so the results equal rtp_resize -> rtp_nms -> rtp_connect bit for bit.
+ * lowres: [num_scales][heat_channels][low_h][low_w]; peaks in/out like rtp_nms (may be NULL). */
+int rtp_post_from_lowres(rtp_engine* e, const float* lowres_host, float* peaks_host, float* joints_host, int* num_people);
+
 /* NmsLayer::Forward_gpu on caller data: resized (C x H x W) -> peaks (num_parts x (max_peaks+1) x 3).
  * peaks is IN/OUT: slots the kernel does not write keep the caller's contents. */
 int rtp_nms(rtp_engine* e, const float* resized_host, float* peaks_host);

@@ -427,3 +427,89 @@ def test_frame_batching_is_transparent(prec_name, B, N):
     tag, n, joints = e.collect()
     assert tag == 77 and n == want[0]["num_people"] and np.array_equal(joints, want[0]["joints"][:n])
     e.close()
+
+
+# ------------------------------------------------------------------------------------------
+# production post-processing (no resized map in memory) == oracle ImResize -> Nms -> connect
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,W,H,N,start,gap,kind", [
+    (0, 656, 368, 1, 1.0, 0.3, "people5"),
+    (0, 656, 368, 3, 1.0, 0.15, "people20"),
+    (1, 496, 368, 2, 1.0, 0.3, "people4"),
+    (0, 656, 368, 1, 1.0, 0.3, "noise"),        # saturates max_peaks: raster-order cap, thousands of PAF candidates
+    (0, 64, 48, 2, 1.0, 0.25, "noise"),         # tiny map: strips shorter than 8 rows, borders everywhere
+    (1, 496, 368, 1, 1.0, 0.3, "noise"),
+])
+def test_fused_postproc_from_lowres_bit_exact(model, W, H, N, start, gap, kind):
+    e = _engine(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, frames_in_flight=1)
+    tabs = orc.model_tables(model)
+    thr = e.get_thresholds()
+    h, w = H // 8, W // 8
+    if kind == "noise":
+        low = (_synth.smooth_field(N * e.heat_channels, h, w, seed=31, scale=1.0).reshape(N, e.heat_channels, h, w)
+               + 0.25 * np.random.default_rng(7).standard_normal((N, e.heat_channels, h, w)).astype(np.float32))
+    else:
+        low, _ = _synth.people_lowres(model, tabs, int(kind[6:]), h, w, seed=44, N=N)
+        low = low.reshape(N, e.heat_channels, h, w)
+    ref_res = orc.imresize(low, W, H, start, gap)[0]
+    ref_peaks = orc.nms(ref_res, e.num_parts, e.max_peaks, thr["nms_threshold"])
+    peaks, joints, n = e.post_from_lowres(low)
+    assert np.array_equal(peaks, ref_peaks)
+    if kind == "noise" and W > 100:
+        assert ref_peaks[:, 0, 0].max() >= e.max_peaks        # the cap was exercised
+    try:
+        rn, rj = orc.connect(model, ref_res, ref_peaks, e.max_peaks, W, H, 1280, 720, thr)
+    except Exception:
+        rn = None
+    if rn is not None:
+        assert n == rn
+        assert np.array_equal(joints[:n], rj[:n])
+    if kind != "noise":
+        assert n >= 1
+    # and the map-materialising taps agree with it too
+    res = e.resize(low)
+    assert np.array_equal(res, ref_res)
+    n2, j2 = e.connect(res, e.nms(res))
+    assert n2 == n and np.array_equal(j2[:n2], joints[:n])
+    e.close()
+
+
+def test_fused_postproc_repeatable_while_another_engine_keeps_the_chip_busy():
+    """The production NMS/connect kernels share CUs with MFMA-heavy convolution workgroups of other
+    frames.  Same low-res maps in => same bits out, however the chip is loaded (this caught packed-f32
+    VALU ops returning different bits inside divergent code under exactly that co-residency)."""
+    import threading
+    import caffe_rtpose_amd as r
+    kw = dict(net_w=320, net_h=176, num_scales=2, scale_gap=0.25, disp_w=640, disp_h=360)
+    a = _engine(frames_in_flight=1, **kw)
+    b = _engine(frames_in_flight=3, **kw)
+    x = r.preprocess_frame(r.synth_frame(800, 600, 0, seed=3), 640, 360, 320, 176, 2, 1.0, 0.25)[0]
+    low = a.forward_debug(x)["lowres"]
+    pk0, j0, n0 = a.post_from_lowres(low)
+    stop = []
+
+    def load():
+        pend = 0
+        while not stop:
+            b.submit(x, tag=0)
+            pend += 1
+            if pend == 3:
+                b.collect()
+                pend -= 1
+        while pend:
+            b.collect()
+            pend -= 1
+
+    t = threading.Thread(target=load)
+    t.start()
+    try:
+        bad = 0
+        for _ in range(250):
+            pk, j, n = a.post_from_lowres(low)
+            bad += not (n == n0 and np.array_equal(pk, pk0) and np.array_equal(j, j0))
+    finally:
+        stop.append(1)
+        t.join()
+    assert bad == 0, f"{bad} of 250 taps differed under load"
+    a.close()
+    b.close()

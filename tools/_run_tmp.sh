@@ -1,1 +1,4 @@
-for b in 1 2 4; do for c in 0 1 2 3 4; do echo "=== B=$b FORCE_CFG=$c"; RTP_FORCE_CFG=$c python tools/prof_steps.py $b 2>&1 | grep -E "ms per batch|k 7 cin_p 128|k 7 cin_p 192|k 3 cin_p 512 cout 512"; done; done
+PROBE_ITERS=1500 python tools/race_probe_post.py load 2>&1 | tail -3
+python tools/_dbg_fused.py host 2>&1 | tail -2
+python tools/_dbg_fused.py frame 2>&1 | tail -2
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
