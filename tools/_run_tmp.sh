@@ -1,4 +1,5 @@
-PROBE_ITERS=1500 python tools/race_probe_post.py load 2>&1 | tail -3
-python tools/_dbg_fused.py host 2>&1 | tail -2
-python tools/_dbg_fused.py frame 2>&1 | tail -2
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf /tmp/pf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf -- python $R/tools/prof_frame.py fp16 1 > /tmp/pf.log 2>&1; grep "conv" /tmp/pf.log | tail -1
+f=$(find /tmp/pf -name "*kernel_stats.csv" | head -1)
+python $R/tools/stats_nonconv.py $f
