@@ -82,6 +82,7 @@ struct Slot {
   float* cand_score = nullptr;
   int* cand_ij = nullptr;
   int* cand_count = nullptr;
+  int* cand_blk = nullptr;
   int* conn = nullptr;
   float* conn_score = nullptr;
   int* conn_count = nullptr;
@@ -669,7 +670,7 @@ ConnectParams connect_params(rtp_engine* e, Ctx& cx, int sj) {
   ConnectParams cp;
   memset(&cp, 0, sizeof cp);
   cp.heat = sl.resized; cp.peaks = sl.peaks; cp.joints = sl.joints; cp.num_people = sl.num_people;
-  cp.cand_score = sl.cand_score; cp.cand_ij = sl.cand_ij; cp.cand_count = sl.cand_count;
+  cp.cand_score = sl.cand_score; cp.cand_ij = sl.cand_ij; cp.cand_count = sl.cand_count; cp.cand_blk = sl.cand_blk;
   cp.conn = sl.conn; cp.conn_score = sl.conn_score; cp.conn_count = sl.conn_count;
   cp.max_rows = e->max_rows; cp.model = e->model; cp.num_parts = e->num_parts; cp.num_limbs = e->num_limbs;
   cp.max_peaks = e->max_peaks; cp.net_w = e->cfg.net_w; cp.net_h = e->cfg.net_h; cp.disp_w = e->cfg.disp_w; cp.disp_h = e->cfg.disp_h;
@@ -741,6 +742,7 @@ int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   HIPCHK(e, hipMalloc((void**)&sl.cand_score, pairs * sizeof(float)));
   HIPCHK(e, hipMalloc((void**)&sl.cand_ij, pairs * sizeof(int)));
   HIPCHK(e, hipMalloc((void**)&sl.cand_count, e->num_limbs * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&sl.cand_blk, (size_t)e->num_limbs * ((e->max_peaks * e->max_peaks + 255) / 256) * sizeof(int)));
   HIPCHK(e, hipMalloc((void**)&sl.conn, (size_t)e->num_limbs * e->max_peaks * 2 * sizeof(int)));
   HIPCHK(e, hipMalloc((void**)&sl.conn_score, (size_t)e->num_limbs * e->max_peaks * sizeof(float)));
   HIPCHK(e, hipMalloc((void**)&sl.conn_count, e->num_limbs * sizeof(int)));
@@ -776,7 +778,7 @@ void free_ctx(Ctx& cx) {
   if (cx.stream) (void)hipStreamSynchronize(cx.stream);
   for (Slot& sl : cx.slot) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
-    void* dptrs[] = {sl.resized, sl.peaks, sl.strip_count, sl.strip_list, sl.cand_score, sl.cand_ij, sl.cand_count, sl.conn, sl.conn_score,
+    void* dptrs[] = {sl.resized, sl.peaks, sl.strip_count, sl.strip_list, sl.cand_score, sl.cand_ij, sl.cand_count, sl.cand_blk, sl.conn, sl.conn_score,
                      sl.conn_count, sl.joints, sl.num_people, sl.frame_dev, sl.disp_dev};
     for (void* p : dptrs) if (p) (void)hipFree(p);
     if (sl.frame_host) (void)hipHostFree(sl.frame_host);

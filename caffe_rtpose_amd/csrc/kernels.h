@@ -138,6 +138,7 @@ struct ConnectParams {
   float* cand_score;   // [num_limbs][max_peaks*max_peaks]
   int* cand_ij;        // [num_limbs][max_peaks*max_peaks]  (i<<16|j), raster (i,j) order, compacted
   int* cand_count;     // [num_limbs]
+  int* cand_blk;       // [num_limbs][ceil(max_peaks^2 / 256)] survivors per block of 256 pairs
   int* conn;           // [num_limbs][max_peaks][2]  (indexA, indexB) flat peak-score indices
   float* conn_score;   // [num_limbs][max_peaks]
   int* conn_count;     // [num_limbs]
@@ -145,6 +146,7 @@ struct ConnectParams {
   double* subset_score;  // [max_rows]
   int* subset_cnt;     // [max_rows]
   int max_rows;
+  int assemble_preload;  // set by launch_connect: the assembly kernel copies its inputs to LDS first
   int model;           // 0 COCO_18, 1 MPI_15
   int num_parts, num_limbs, max_peaks;
   int net_w, net_h, disp_w, disp_h;

@@ -24,17 +24,15 @@
 #include "kernels.h"
 #include "stdsort_replica.h"
 
-// No packed-f32 VALU (v_pk_add/mul/fma_f32) in these kernels.  hipcc's SLP vectoriser pairs the x/y
-// halves of the scalar float math below into packed ops; with that, nms_fused_write_kernel returned
-// run-to-run different bits for the SAME inputs (whole 16-lane groups, inside divergent code) whenever
-// MFMA-heavy convolution workgroups of another frame shared its CU, and never on an idle chip
-// (tools/race_probe_post.py; in-kernel re-evaluation self-check).  Scalar f32 ops are bit-identical
-// by definition, and with them 0 mismatches in the same stress.  Cost: nothing measurable.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RTP_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define RTP_NO_PK_F32
-#endif
+// No packed-f32 VALU (v_pk_add/mul/fma_f32) in these kernels: this file is built with
+// -fno-slp-vectorize -fno-vectorize (csrc/Makefile BITEXACT; `make check-nopk` and a CPU test count
+// the instructions).  hipcc's SLP vectoriser pairs the x/y halves of the scalar float math below
+// into packed ops; with that, nms_fused_write_kernel returned run-to-run different bits for the SAME
+// inputs (whole 16-lane groups, inside divergent code) whenever MFMA-heavy convolution workgroups
+// of another frame shared its CU, and never on an idle chip (tools/race_probe_post.py; in-kernel
+// re-evaluation self-check).  Scalar f32 ops are bit-identical by definition, and with them 0
+// mismatches in the same stress.  (A per-function target("no-packed-fp32-ops") also removes them
+// but blocks inlining of the HIP header/ockl functions: __syncthreads became a call.)
 
 namespace rtp {
 
@@ -110,7 +108,7 @@ __device__ __forceinline__ float resized_at(const ResizeParams& p, int c, int y,
 // instead of 5) and the 16 neighbours are loaded once per block.  Per-output arithmetic and
 // rounding are exactly the reference kernel's; whenever the neighbourhood of an output differs
 // from the previous one (other scales, borders) it is simply recomputed.
-__global__ RTP_NO_PK_F32 __launch_bounds__(128) void resize_kernel(ResizeParams p) {
+__global__ __launch_bounds__(128) void resize_kernel(ResizeParams p) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;  // 8-wide column strip
   const int x0 = 8 * k - 4;
   const int y0 = 8 * (int)blockIdx.y - 4;
@@ -224,7 +222,7 @@ __device__ __forceinline__ int nms_flag(const float* s, int x, int y, int W, int
   return 0;
 }
 
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_strip_kernel(NmsParams p) {
+__global__ __launch_bounds__(256) void nms_strip_kernel(NmsParams p) {
   __shared__ int wave_cnt[4];
   __shared__ int running;
   const int strip = blockIdx.x, part = blockIdx.y;
@@ -258,7 +256,7 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_strip_kernel(NmsParams 
   if (tid == 0) p.strip_count[part * p.nstrips + strip] = running;
 }
 
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
+__global__ __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
   extern __shared__ int prefix[];  // [nstrips+1]
   const int part = blockIdx.x;
   const int tid = threadIdx.x;
@@ -314,7 +312,7 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_write_kernel(NmsParams 
 // low-res rows the strip touches, then the column interpolation, accumulated over the scales in
 // scale order — the arithmetic of resize_kernel), then flagged exactly like nms_strip_kernel.
 #define NMSF_TROWS 8
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, ResizeParams r) {
+__global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, ResizeParams r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = p.W, H = p.H;
   float* out = (float*)lds_raw;                 // [strip_rows + 2][W]
@@ -380,30 +378,42 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_strip_kernel(NmsP
   const int pix0 = y0 * W;
   int* list = p.strip_list + ((long)part * p.nstrips + strip) * p.max_peaks;
   const float* s = out - (long)ya * W;  // s[y * W + x] for y in ya..yb
-  for (int base = 0; base < npix; base += 256) {
-    const int q = base + tid;
+  // Raster-order ordinals with two barriers: wave w owns the w-th quarter of the strip's pixels
+  // (64-pixel groups, contiguous), keeps one ballot per group in LDS (T is free now) and counts;
+  // after the wave totals are exchanged every maximum knows its ordinal.
+  unsigned long long* bals = (unsigned long long*)T;
+  const int ngroups = (npix + 63) / 64;
+  const int gper = (ngroups + 3) / 4;
+  const int g0 = wave * gper, g1 = min(g0 + gper, ngroups);
+  int mine = 0;
+  for (int g = g0; g < g1; ++g) {
+    const int q = g * 64 + lane;
     int f = 0;
     if (q < npix) {
       const int gq = pix0 + q;
       f = nms_flag(s, gq % W, gq / W, W, H, p.threshold);
     }
     const unsigned long long bal = __ballot(f);
-    if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int before = running;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (f && ord < p.max_peaks) list[ord] = pix0 + q;
-    __syncthreads();
-    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
+    if (lane == 0) bals[g] = bal;
+    mine += __popcll(bal);
   }
+  if (lane == 0) wave_cnt[wave] = mine;
+  __syncthreads();
+  int ord0 = 0;
+  for (int w = 0; w < wave; ++w) ord0 += wave_cnt[w];
+  for (int g = g0; g < g1 && ord0 < p.max_peaks; ++g) {
+    const unsigned long long bal = bals[g];
+    const int ord = ord0 + __popcll(bal & ((1ull << lane) - 1ull));
+    if (((bal >> lane) & 1) && ord < p.max_peaks) list[ord] = pix0 + g * 64 + lane;
+    ord0 += __popcll(bal);
+  }
+  if (tid == 0) running = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
   if (tid == 0) p.strip_count[part * p.nstrips + strip] = running;
 }
 
 // Write kernel: the 49 window values of every kept peak are evaluated on demand by all threads,
 // then one thread per peak accumulates them in the reference's (dy, dx) order.
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, ResizeParams r) {
+__global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, ResizeParams r) {
   extern __shared__ int dyn_i[];
   int* prefix = dyn_i;                                   // [nstrips+1]
   float* win = (float*)(dyn_i + p.nstrips + 1);          // [max_peaks][50]: 49 window values + centre
@@ -422,11 +432,16 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_write_kernel(NmsP
   const int total = prefix[p.nstrips];
   const int W = p.W, H = p.H;
   float* dst = p.peaks + (long)part * (p.max_peaks + 1) * 3;
-  const int n = total < p.max_peaks ? total : p.max_peaks;
+  const int nall = total < p.max_peaks ? total : p.max_peaks;
+  // this workgroup's share of the part's peaks: ordinals e0 .. e0+n-1 (local index e below)
+  const int share = (nall + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int e0 = (int)blockIdx.y * share;
+  const int n = max(0, min(share, nall - e0));
   for (int e = tid; e < n; e += 256) {
+    const int ge = e0 + e;
     int st = 0;
-    while (prefix[st + 1] <= e) ++st;  // strip holding ordinal e
-    pix[e] = p.strip_list[((long)part * p.nstrips + st) * p.max_peaks + (e - prefix[st])];
+    while (prefix[st + 1] <= ge) ++st;  // strip holding ordinal ge
+    pix[e] = p.strip_list[((long)part * p.nstrips + st) * p.max_peaks + (ge - prefix[st])];
   }
   __syncthreads();
   for (int it = tid; it < n * 50; it += 256) {
@@ -465,12 +480,12 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void nms_fused_write_kernel(NmsP
         }
       }
     }
-    const int oi = (e + 1) * 3;
+    const int oi = (e0 + e + 1) * 3;
     dst[oi] = x_acc / score_acc;
     dst[oi + 1] = y_acc / score_acc;
     dst[oi + 2] = win[e * 50 + 49];
   }
-  if (tid == 0) dst[0] = (float)total;  // unclamped total, nms_layer.cu:110
+  if (tid == 0 && blockIdx.y == 0) dst[0] = (float)total;  // unclamped total, nms_layer.cu:110
 }
 
 hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream) {
@@ -484,7 +499,7 @@ hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const size_t lds2 = (p.nstrips + 1) * sizeof(int) + (size_t)p.max_peaks * 51 * sizeof(float);
-  hipLaunchKernelGGL(nms_fused_write_kernel, dim3(p.num_parts), dim3(256), lds2, stream, p, r);
+  hipLaunchKernelGGL(nms_fused_write_kernel, dim3(p.num_parts, 4), dim3(256), lds2, stream, p, r);
   return hipGetLastError();
 }
 
@@ -509,7 +524,8 @@ __constant__ int kMpiMap[28] = {16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 
 // connectLimbs* in three kernels (all bit-exact restatements; -ffp-contract=off):
 //  connect_pairs_kernel    grid (ceil(max_peaks^2/256), limbs): the PAF line integral of every (i,j)
 //      candidate pair (rtpose.cpp:897-951 / :611-651), one pair per thread, result to global
-//      scratch in the reference's loop order q = (i-1)*nB + (j-1): cand_ij[q] = 0 when the pair fails.
+//      scratch: the survivors of each block of 256 pairs (loop order q = (i-1)*nB + (j-1)) compacted
+//      at the head of the block's slots, their count in cand_blk.
 //  connect_match_kernel    one workgroup per limb: compacts the survivors in loop order, orders them
 //      as std::sort(.., ColumnCompare) would (:953-954) and runs the greedy assignment (:956-980).
 //      If all scores are distinct the sorted order is unique, so a bitonic sort on the 64-bit key
@@ -532,7 +548,7 @@ __device__ __forceinline__ void limb_setup(const ConnectParams& p, int k, const 
 }
 
 template <bool FUSED>
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, ResizeParams r) {
+__global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, ResizeParams r) {
   const int k = blockIdx.y;
   const int cap = p.max_peaks * p.max_peaks;
   const bool coco = p.model == 0;
@@ -543,12 +559,18 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_pairs_kernel(Connec
   const float *candA, *candB;
   int nA, nB;
   limb_setup(p, k, candA, candB, nA, nB);
+  __shared__ int wave_cnt[4];
   const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nA * nB) return;
+  const int npairs = nA * nB;
+  if (blockIdx.x * 256 >= npairs) {  // whole block past the last pair (uniform)
+    if (threadIdx.x == 0) p.cand_blk[k * gridDim.x + blockIdx.x] = 0;
+    return;
+  }
   const int num_inter = 10;
   int pass = 0;
   float conn_score = 0.f;
-  const int i = q / nB + 1, j = q % nB + 1;
+  const int i = q / (nB > 0 ? nB : 1) + 1, j = q % (nB > 0 ? nB : 1) + 1;
+  if (q < npairs) {
   const float s_x = candA[i * 3];
   const float s_y = candA[i * 3 + 1];
   const float d_x = candB[j * 3] - candA[i * 3];
@@ -600,8 +622,20 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_pairs_kernel(Connec
       conn_score = sum / count;
     }
   }
-  p.cand_score[(long)k * cap + q] = conn_score;
-  p.cand_ij[(long)k * cap + q] = pass ? ((i << 16) | j) : 0;
+  }
+  // survivors of this block, compacted in loop order at the head of the block's 256 slots
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(pass);
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+  const int lo = before + __popcll(bal & ((1ull << lane) - 1ull));
+  if (pass) {
+    p.cand_score[(long)k * cap + blockIdx.x * 256 + lo] = conn_score;
+    p.cand_ij[(long)k * cap + blockIdx.x * 256 + lo] = (i << 16) | j;
+  }
+  if (threadIdx.x == 0) p.cand_blk[k * gridDim.x + blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
 // 64-bit sort key: ascending key order == (score descending, loop order ascending)
@@ -616,10 +650,9 @@ __device__ __forceinline__ float key_score(unsigned long long key) {
   return __uint_as_float(u);
 }
 
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
+__global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned long long* keys = (unsigned long long*)lds_raw;  // [pow2 >= survivors]
-  __shared__ int wave_cnt[4];
   __shared__ int running;
   __shared__ int flags;  // 1: NaN score seen   2: greedy scan met an ambiguous tie
   __shared__ int s_cnt;
@@ -641,26 +674,23 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_match_kernel(Connec
   const int npairs = nA * nB;
   const float* gs = p.cand_score + (long)k * cap;
   const int* gij = p.cand_ij + (long)k * cap;
-  // ---- survivors, compacted in loop order
-  auto compact = [&](auto&& put) {
-    for (int base = 0; base < npairs; base += 256) {
-      const int q = base + tid;
-      int ij = 0;
-      float sc = 0.f;
-      if (q < npairs) { ij = gij[q]; sc = gs[q]; }
-      const unsigned long long bal = __ballot(ij != 0);
-      if (lane == 0) wave_cnt[wave] = __popcll(bal);
-      __syncthreads();
-      int before = running;
-      for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-      const int ord = before + __popcll(bal & ((1ull << lane) - 1ull));
-      if (ij) put(ord, sc, ij);
-      __syncthreads();
-      if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-      __syncthreads();
+  // ---- survivors in loop order: the pair kernel compacted each block of 256; gather the blocks
+  const int nblk = (npairs + 255) / 256, blk_stride = (cap + 255) / 256;
+  __shared__ int blk_off[65];
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) { blk_off[b] = run; run += p.cand_blk[k * blk_stride + b]; }
+    blk_off[nblk] = run;
+    running = run;
+  }
+  __syncthreads();
+  auto gather = [&](auto&& put) {
+    for (int b = 0; b < nblk; ++b) {
+      const int o = blk_off[b], c = blk_off[b + 1] - o;
+      if (tid < c) put(o + tid, gs[b * 256 + tid], gij[b * 256 + tid]);
     }
   };
-  compact([&](int ord, float sc, int ij) {
+  gather([&](int ord, float sc, int ij) {
     if (!(sc == sc)) flags = 1;  // NaN breaks the ordering: force the exact path
     keys[ord] = match_key(sc, ord, ij >> 16, ij & 0xffff);
   });
@@ -734,9 +764,8 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_match_kernel(Connec
   __syncthreads();
   if (flags) {  // exact path: the survivors again in loop order, then libstdc++'s introsort on lane 0
     Cand* cands = (Cand*)lds_raw;
-    if (tid == 0) running = 0;
+    gather([&](int ord, float sc, int ij) { cands[ord].score = sc; cands[ord].ij = ij; });
     __syncthreads();
-    compact([&](int ord, float sc, int ij) { cands[ord].score = sc; cands[ord].ij = ij; });
     if (tid == 0) {
       std_sort_replica(cands, nc);
       int cnt = 0;
@@ -772,7 +801,7 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_match_kernel(Connec
 // written, so the scan can be turned inside out: ONE pass over the rows looks up the connection
 // owning the row's partA peak (conn_of[]), updates the row, and marks the connection as matched;
 // unmatched connections then append their rows in connection order, exactly as the serial loop.
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
+__global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int NP = p.num_parts;
   double* sscore = (double*)lds_raw;                       // [max_rows]
@@ -785,8 +814,26 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_assemble_kernel(Con
   const bool coco = p.model == 0;
   const int* limbSeq = coco ? kCocoLimb : kMpiLimb;
   const int peaks_offset = 3 * (p.max_peaks + 1);
-  const float* peaks = p.peaks;
   if (*p.num_people < 0) return;  // the pair kernel flagged out-of-contract data
+  // Everything the serial limb loop reads (peaks, connections, their scores and counts) is pulled
+  // into LDS first with independent loads; the loop then never waits on global memory.
+  const float* peaks = p.peaks;
+  const int* conn_all = p.conn;
+  const float* cs_all = p.conn_score;
+  const int* ncon_all = p.conn_count;
+  if (p.assemble_preload) {
+    float* l_peaks = (float*)(lds_raw + (((size_t)p.max_rows * (sizeof(double) + sizeof(short) + sizeof(short) * NP) + 7) & ~(size_t)7));
+    const int npk = NP * peaks_offset;
+    int* l_conn = (int*)(l_peaks + npk);
+    float* l_cs = (float*)(l_conn + p.num_limbs * p.max_peaks * 2);
+    int* l_ncon = (int*)(l_cs + p.num_limbs * p.max_peaks);
+    for (int i = tid; i < npk; i += 256) l_peaks[i] = p.peaks[i];
+    for (int i = tid; i < p.num_limbs * p.max_peaks * 2; i += 256) l_conn[i] = p.conn[i];
+    for (int i = tid; i < p.num_limbs * p.max_peaks; i += 256) l_cs[i] = p.conn_score[i];
+    if (tid < p.num_limbs) l_ncon[tid] = p.conn_count[tid];
+    __syncthreads();
+    peaks = l_peaks; conn_all = l_conn; cs_all = l_cs; ncon_all = l_ncon;
+  }
   int nrows = 0;                  // uniform over the workgroup
 
   // rows for the items (tid < n) whose `want` is set, appended in item order
@@ -811,9 +858,11 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_assemble_kernel(Con
 
   for (int k = 0; k < p.num_limbs; ++k) {
     const int partA = limbSeq[2 * k], partB = limbSeq[2 * k + 1];
-    const float *candA, *candB;
-    int nA, nB;
-    limb_setup(p, k, candA, candB, nA, nB);
+    const float* candA = peaks + partA * peaks_offset;
+    const float* candB = peaks + partB * peaks_offset;
+    int nA = (int)candA[0], nB = (int)candB[0];
+    if (nA > p.max_peaks) nA = p.max_peaks;  // defined-behaviour clamp (see oracle NOTE)
+    if (nB > p.max_peaks) nB = p.max_peaks;
     if (nA == 0 && nB == 0) continue;
     if (nA == 0 || nB == 0) {
       const int part = (nA == 0) ? partB : partA;
@@ -833,9 +882,9 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void connect_assemble_kernel(Con
       append_rows(n, want, part, part * peaks_offset + i * 3 + 2, -1, 0, 1, tid < n ? (double)cand[i * 3 + 2] : 0.0);
       continue;
     }
-    const int nconn = p.conn_count[k];
-    const int* conn = p.conn + (long)k * p.max_peaks * 2;
-    const float* cs = p.conn_score + (long)k * p.max_peaks;
+    const int nconn = ncon_all[k];
+    const int* conn = conn_all + (long)k * p.max_peaks * 2;
+    const float* cs = cs_all + (long)k * p.max_peaks;
     if (k != 0 && nconn == 0) continue;
     int indexA = 0, indexB = 0;
     float csv = 0.f;
@@ -906,8 +955,14 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
   size_t n2 = 64;
   while ((int)n2 < cap) n2 <<= 1;
   const size_t lds1 = n2 * sizeof(unsigned long long);
-  const size_t lds2 = (size_t)p.max_rows * (sizeof(double) + sizeof(short) + sizeof(short) * p.num_parts);
+  size_t lds2 = (size_t)p.max_rows * (sizeof(double) + sizeof(short) + sizeof(short) * p.num_parts);
   if (p.max_peaks > 127) return hipErrorInvalidValue;
+  ConnectParams pa = p;
+  {
+    const size_t extra = 8 + ((size_t)p.num_parts * 3 * (p.max_peaks + 1) + (size_t)p.num_limbs * p.max_peaks * 3 + p.num_limbs) * 4;
+    pa.assemble_preload = (lds2 + extra <= 150 * 1024) ? 1 : 0;
+    if (pa.assemble_preload) lds2 += extra;
+  }
   if (lds1 > 64 * 1024) {
     e = hipFuncSetAttribute((const void*)connect_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return e;
@@ -923,7 +978,7 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
   hipLaunchKernelGGL(connect_match_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(256), lds2, stream, p);
+  hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(256), lds2, stream, pa);
   return hipGetLastError();
 }
 

@@ -11,16 +11,11 @@
 
 #include "kernels.h"
 
-// see postproc.hip: no packed-f32 VALU in bit-exact kernels that share CUs with MFMA workgroups
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RTP_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define RTP_NO_PK_F32
-#endif
+// built with the BITEXACT flags of csrc/Makefile (no packed-f32 VALU; see postproc.hip)
 
 namespace rtp {
 
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void warp_cubic_kernel(const unsigned char* __restrict__ src, int sw, int sh, double inv,
+__global__ __launch_bounds__(256) void warp_cubic_kernel(const unsigned char* __restrict__ src, int sw, int sh, double inv,
                                                          WarpTab tab, unsigned char* __restrict__ dst, int dw, int dh) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
@@ -59,7 +54,7 @@ __global__ RTP_NO_PK_F32 __launch_bounds__(256) void warp_cubic_kernel(const uns
 }
 
 // One thread per pixel of the (net_w x net_h) frame of scale `blockIdx.z`.
-__global__ RTP_NO_PK_F32 __launch_bounds__(256) void area_pad_kernel(const unsigned char* __restrict__ disp, int dw, int dh, AreaScale sc0, AreaScale sc1,
+__global__ __launch_bounds__(256) void area_pad_kernel(const unsigned char* __restrict__ disp, int dw, int dh, AreaScale sc0, AreaScale sc1,
                                                        AreaScale sc2, AreaScale sc3, int nscales_in_launch, float* __restrict__ out, int net_w,
                                                        int net_h, int scale_base) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;

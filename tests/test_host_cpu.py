@@ -303,3 +303,16 @@ def test_stdsort_replica_matches_libstdcxx(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tests", "helpers", "stdsort_check.cpp")])
     out = subprocess.check_output([str(exe), "1500"]).decode()
     assert out.startswith("OK"), out
+
+
+def test_bit_exact_kernels_contain_no_packed_f32_valu():
+    """postproc.hip / preproc.hip must compile without v_pk_*_f32: with them the
+    production NMS kernel was not repeatable under MFMA co-residency on gfx950."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "caffe_rtpose_amd", "csrc"), "check-nopk"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    counts = [int(x) for x in out.stdout.split()]
+    assert counts == [0, 0], out.stdout
