@@ -80,13 +80,13 @@ __device__ __forceinline__ float axis_nb(int x, float offset, float f, int osize
 }
 // ONE output of the resized map, computed exactly as resize_kernel computes it (same operations in
 // the same order per scale, same accumulation over scales).
-__device__ __forceinline__ float resized_at(const ResizeParams& p, int c, int y, int x) {
-  const long plane = (long)p.h * p.w;
-  const float* src_c = p.src + (long)c * plane;
+// chan0: the channel's map at scale 0; scale_stride: floats between consecutive scales of that channel;
+// geo: the per-scale geometry (scale_geo), computed once per workgroup
+__device__ __forceinline__ float resized_from(const ScaleGeo* geo, int num, const float* chan0, long scale_stride, int y, int x) {
   float sum = 0.f;
-  for (int n = 0; n < p.num; ++n) {
-    const ScaleGeo g = scale_geo(p, n);
-    const float* sp = src_c + (long)n * p.C * plane;
+  for (int n = 0; n < num; ++n) {
+    const ScaleGeo g = geo[n];
+    const float* sp = chan0 + (long)n * scale_stride;
     int xn[4], yn[4];
     const float dx = axis_nb(x, g.offset_x, g.fx, g.ow, g.padw, xn);
     const float dy = axis_nb(y, g.offset_y, g.fy, g.oh, g.padh, yn);
@@ -99,7 +99,41 @@ __device__ __forceinline__ float resized_at(const ResizeParams& p, int c, int y,
     const float d = cubic_interp(t[0], t[1], t[2], t[3], dy);
     sum = sum + d;
   }
-  return sum / p.num;
+  return sum / num;
+}
+// two channels at the same output pixel (the x and y PAF of a limb): the neighbourhood is shared
+__device__ __forceinline__ void resized_pair(const ScaleGeo* geo, int num, const float* cx0, const float* cy0, long scale_stride, int y, int x,
+                                             float* vx, float* vy) {
+  float sx = 0.f, sy = 0.f;
+  for (int n = 0; n < num; ++n) {
+    const ScaleGeo g = geo[n];
+    const float* spx = cx0 + (long)n * scale_stride;
+    const float* spy = cy0 + (long)n * scale_stride;
+    int xn[4], yn[4];
+    const float dx = axis_nb(x, g.offset_x, g.fx, g.ow, g.padw, xn);
+    const float dy = axis_nb(y, g.offset_y, g.fy, g.oh, g.padh, yn);
+    float tx[4], ty[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ro = yn[i] * g.rw;
+      tx[i] = cubic_interp(spx[ro + xn[0]], spx[ro + xn[1]], spx[ro + xn[2]], spx[ro + xn[3]], dx);
+      ty[i] = cubic_interp(spy[ro + xn[0]], spy[ro + xn[1]], spy[ro + xn[2]], spy[ro + xn[3]], dx);
+    }
+    sx = sx + cubic_interp(tx[0], tx[1], tx[2], tx[3], dy);
+    sy = sy + cubic_interp(ty[0], ty[1], ty[2], ty[3], dy);
+  }
+  *vx = sx / num;
+  *vy = sy / num;
+}
+#define RTP_MAX_SCALES 16
+// every thread calls; geo[] (LDS) is valid after the barrier inside
+__device__ __forceinline__ void fill_scale_geo(ScaleGeo* geo, const ResizeParams& p) {
+  if ((int)threadIdx.x < p.num) geo[threadIdx.x] = scale_geo(p, threadIdx.x);
+  __syncthreads();
+}
+__device__ __forceinline__ float resized_at(const ScaleGeo* geo, const ResizeParams& p, int c, int y, int x) {
+  const long plane = (long)p.h * p.w;
+  return resized_from(geo, p.num, p.src + (long)c * plane, (long)p.C * plane, y, x);
 }
 
 // One thread = an 8x8 block of outputs of one channel: x0 = 8k-4, y0 = 8m-4.  For the full-size
@@ -420,6 +454,7 @@ __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, Resiz
   int* pix = (int*)(win + p.max_peaks * 50);             // [max_peaks]
   const int part = blockIdx.x;
   const int tid = threadIdx.x;
+  __shared__ ScaleGeo geo[RTP_MAX_SCALES];
   if (tid == 0) {
     int run = 0;
     for (int i = 0; i < p.nstrips; ++i) {
@@ -428,7 +463,7 @@ __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, Resiz
     }
     prefix[p.nstrips] = run;
   }
-  __syncthreads();
+  fill_scale_geo(geo, r);
   const int total = prefix[p.nstrips];
   const int W = p.W, H = p.H;
   float* dst = p.peaks + (long)part * (p.max_peaks + 1) * 3;
@@ -448,7 +483,7 @@ __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, Resiz
     const int e = it / 50, wq = it - e * 50;
     const int px = pix[e] % W, py = pix[e] / W;
     float score = 0.f;
-    if (wq == 49) score = resized_at(r, part, py, px);
+    if (wq == 49) score = resized_at(geo, r, part, py, px);
     else {
       const int dy = wq / 7 - 3, dx = wq % 7 - 3;
       // writeResultKernel, nms_layer.cu:70-105: the bound on y is `width`, so the window may run
@@ -456,7 +491,7 @@ __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, Resiz
       if ((py + dy) > 0 && (py + dy) < W && (px + dx) > 0 && (px + dx) < W) {
         const int row = py + dy;
         const int pl = part + row / H;
-        if (pl < p.src_planes) score = resized_at(r, pl, row % H, px + dx);
+        if (pl < p.src_planes) score = resized_at(geo, r, pl, row % H, px + dx);
       }
     }
     win[it] = score;
@@ -548,7 +583,8 @@ __device__ __forceinline__ void limb_setup(const ConnectParams& p, int k, const 
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, ResizeParams r) {
+__global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, ResizeParams r, int stage) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int k = blockIdx.y;
   const int cap = p.max_peaks * p.max_peaks;
   const bool coco = p.model == 0;
@@ -565,6 +601,21 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, Res
   if (blockIdx.x * 256 >= npairs) {  // whole block past the last pair (uniform)
     if (threadIdx.x == 0) p.cand_blk[k * gridDim.x + blockIdx.x] = 0;
     return;
+  }
+  // FUSED: the limb's two PAF channels (all scales) go to LDS once per workgroup; the 20 bicubic
+  // samples of a pair (16 taps each per scale) then never leave the CU
+  const long lplane = (long)r.h * r.w;
+  float* lmap = (float*)lds_raw;  // [2][num][h][w]
+  __shared__ ScaleGeo geo[RTP_MAX_SCALES];
+  if (FUSED) fill_scale_geo(geo, r);
+  if (FUSED && stage) {
+    const int per = r.num * (int)lplane;
+    for (int t = threadIdx.x; t < 2 * per; t += 256) {
+      const int which = t / per, rem = t - which * per;
+      const int n = rem / (int)lplane, o = rem - n * (int)lplane;
+      lmap[t] = r.src[((long)n * r.C + mapIdx[2 * k + which]) * lplane + o];
+    }
+    __syncthreads();
   }
   const int num_inter = 10;
   int pass = 0;
@@ -599,8 +650,8 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, Res
     for (int lm = 0; lm < num_inter; lm++) {
       if (FUSED) {  // the two PAF samples straight from the low-res maps (no resized map in memory)
         const int my = idxs[lm] / NW, mx = idxs[lm] - my * NW;
-        px[lm] = resized_at(r, mapIdx[2 * k], my, mx);
-        py[lm] = resized_at(r, mapIdx[2 * k + 1], my, mx);
+        if (stage) resized_pair(geo, r.num, lmap, lmap + r.num * lplane, lplane, my, mx, &px[lm], &py[lm]);
+        else resized_pair(geo, r.num, r.src + (long)mapIdx[2 * k] * lplane, r.src + (long)mapIdx[2 * k + 1] * lplane, (long)r.C * lplane, my, mx, &px[lm], &py[lm]);
       } else {
         px[lm] = map_x[idxs[lm]];
         py[lm] = map_y[idxs[lm]];
@@ -685,9 +736,23 @@ __global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
   }
   __syncthreads();
   auto gather = [&](auto&& put) {
-    for (int b = 0; b < nblk; ++b) {
-      const int o = blk_off[b], c = blk_off[b + 1] - o;
-      if (tid < c) put(o + tid, gs[b * 256 + tid], gij[b * 256 + tid]);
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+      float sc[8];
+      int ij[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // 16 independent loads in flight
+        const int idx = min((b0 + u) * 256 + tid, cap - 1);
+        sc[u] = gs[idx];
+        ij[u] = gij[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u;
+        if (b < nblk) {
+          const int o = blk_off[b], c = blk_off[b + 1] - o;
+          if (tid < c) put(o + tid, sc[u], ij[u]);
+        }
+      }
     }
   };
   gather([&](int ord, float sc, int ij) {
@@ -700,14 +765,36 @@ __global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
   for (int t = nc + tid; t < n2; t += 256) keys[t] = ~0ull;
   __syncthreads();
   // ---- bitonic sort, ascending keys
+  const int half = n2 >> 1;
   for (int kk = 2; kk <= n2; kk <<= 1) {
     for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-      for (int t = tid; t < (n2 >> 1); t += 256) {
-        const int a = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-        const int b = a | jj;
-        const unsigned long long ka = keys[a], kb = keys[b];
-        const bool up = (a & kk) == 0;
-        if ((ka > kb) == up) { keys[a] = kb; keys[b] = ka; }
+      if (half >= 2048) {  // 8+ pairs per thread: all reads of a group first, branch-free writes
+        for (int t0 = tid; t0 < half; t0 += 2048) {
+          unsigned long long ka[8], kb[8];
+          int ia[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * 256;
+            ia[u] = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+            ka[u] = keys[ia[u]];
+            kb[u] = keys[ia[u] | jj];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool sw = (ka[u] > kb[u]) == ((ia[u] & kk) == 0);
+            keys[ia[u]] = sw ? kb[u] : ka[u];
+            keys[ia[u] | jj] = sw ? ka[u] : kb[u];
+          }
+        }
+      } else {
+        for (int t = tid; t < half; t += 256) {
+          const int a = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+          const int b = a | jj;
+          const unsigned long long ka = keys[a], kb = keys[b];
+          const bool sw = (ka > kb) == ((a & kk) == 0);
+          keys[a] = sw ? kb : ka;
+          keys[b] = sw ? ka : kb;
+        }
       }
       __syncthreads();
     }
@@ -971,8 +1058,15 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
     e = hipFuncSetAttribute((const void*)connect_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
   }
-  if (r) hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p, *r);
-  else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p, ResizeParams{});
+  if (r) {
+    const size_t lds0 = (size_t)2 * r->num * r->h * r->w * sizeof(float);
+    const int stage = lds0 <= 96 * 1024 ? 1 : 0;
+    if (stage && lds0 > 64 * 1024) {
+      e = hipFuncSetAttribute((const void*)connect_pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), stage ? lds0 : 0, stream, p, *r, stage);
+  } else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p, ResizeParams{}, 0);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(connect_match_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
