@@ -39,6 +39,9 @@ def cpu_baseline(eng, num_scales):
             "sample": f"1 frame, {num_scales} scale(s), 656x368 COCO: conv stack {t1 - t0:.2f}s + postproc {t2 - t1:.2f}s, OpenMP fp32"}
 
 
+PMC_B2 = None  # (FETCH_SIZE KiB, WRITE_SIZE KiB) per dominant launch at batch_frames=2, from profiles/r01_dominant_conv_pmc.txt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,7 +51,7 @@ def main():
     ap.add_argument("--scale_gap", type=float, default=0.3)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--in_flight", type=int, default=8)
-    ap.add_argument("--batch_frames", type=int, default=1, help="frames whose conv stacks share one launch sequence")
+    ap.add_argument("--batch_frames", type=int, default=2, help="frames whose conv stacks share one launch sequence (1 = the reference's one frame per Forward)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,6 +80,7 @@ def main():
     torch.cuda.synchronize()
 
     lat = []
+    host = {"submit": 0.0, "collect": 0.0, "frames": 0}
 
     def run(nsteps, base_tag):
         sub = col = 0
@@ -87,10 +91,16 @@ def main():
                 t_sub[sub] = time.perf_counter()
                 eng.submit_device(frames[sub % nframes].data_ptr(), tag=base_tag + sub)
                 sub += 1
+                if base_tag:
+                    host["submit"] += time.perf_counter() - t_sub[sub - 1]
+            t_c = time.perf_counter()
             tag, n, _ = eng.collect()
             assert tag == base_tag + col
             if base_tag:
-                lat.append(time.perf_counter() - t_sub.pop(col))
+                now = time.perf_counter()
+                host["collect"] += now - t_c
+                host["frames"] += 1
+                lat.append(now - t_sub.pop(col))
             people += n
             col += 1
         return people
@@ -112,8 +122,11 @@ def main():
         peak = 2.5e15 if args.precision == "fp16" else 157.3e12
         ms = dom_ms / max(dom_n, 1)   # average launch duration inside the timed, pipelined region
         achieved = dom_flops / (ms * 1e-3)
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)
-        traffic = (2 * 6001 + 1886) * 1024 if args.num_scales == 1 else None
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE/WRITE_SIZE are in KiB;
+        # FETCH_SIZE x2 per the guide's gfx950 correction), keyed by (num_scales, batch_frames); None = not collected
+        pmc_kib = {(1, 1): (6458, 1886), (1, 2): PMC_B2}
+        fw = pmc_kib.get((args.num_scales, args.batch_frames))
+        traffic = (2 * fw[0] + fw[1]) * 1024 if fw else None
         roof = {"bound": "mfma", "kernel": "conv_ring_kernel 7x7 128->128 (L1+L2 branch pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "ms_per_launch": ms, "launches_timed": dom_n,
                 "flops_per_launch": dom_flops}
@@ -128,9 +141,11 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"COCO 656x368, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU in batches of {args.batch_frames}, synthetic weights",
+                       "batch_frames": args.batch_frames, "frames_in_flight": args.in_flight, "num_scales": args.num_scales,
                        "parallelism": f"frame-sharded replicas x{world}"},
             "latency_ms": {"p50_pipelined": float(np.percentile(lat, 50) * 1e3), "p95_pipelined": float(np.percentile(lat, 95) * 1e3),
                            "single_frame_device": stage["total"]},
+            "host_ms_per_frame": {"submit_calls": host["submit"] / max(host["frames"], 1) * 1e3, "collect_calls_incl_wait": host["collect"] / max(host["frames"], 1) * 1e3},
             "stage_ms_last_frame": stage, "roofline": roof, "conv_stack_whole_frame": whole,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,12 +1,11 @@
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-PROBE_ITERS=600 python tools/race_probe_post.py load 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf /tmp/pf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf -- python $R/tools/prof_frame.py fp16 1 > /tmp/pf.log 2>&1; grep "conv" /tmp/pf.log | tail -1
-python $R/tools/stats_nonconv.py $(find /tmp/pf -name "*kernel_stats.csv" | head -1)
-cd $R
-P='import sys,json
-d=json.loads(sys.stdin.read()); print(round(d["value"],1), "fps  p50", round(d["latency_ms"]["p50_pipelined"],2), "ms  roof", round(d["roofline"]["frac"],3), "whole", round(d["conv_stack_whole_frame"]["frac"],3), d["stage_ms_last_frame"])'
-run() { echo "== B=$B F=$F N=${N:-1} $*"; env "$@" timeout 300 python bench.py --no_cpu_baseline --steps 600 --warmup 60 --batch_frames $B --in_flight $F --num_scales ${N:-1} --scale_gap 0.15 2>&1 | tail -1 | python -c "$P"; }
-B=1 F=8;  run X=1
-B=2 F=8; run X=1
+O=$R/gpurun_out/pmc_b2.txt
+echo "# RTP_DIAG_SKIP_POST=2 rocprofv3 --kernel-trace --pmc <group> -- python tools/prof_dominant.py fp16 20 2   (one group per pass; batch_frames=2 -> tile 128x64)" > $O
+export RTP_DIAG_SKIP_POST=2
+for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"; do
+  rm -rf /tmp/pmc; timeout 60 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc -- python $R/tools/prof_dominant.py fp16 20 2 > /tmp/pmc.log 2>&1; rc=$?; echo "group '$grp' rc=$rc"
+  if [ $rc -ne 0 ]; then echo "# group '$grp': rocprofv3 rc=$rc" >> $O; [ $rc -eq 124 ] && break; continue; fi
+  timeout 20 python $R/tools/pmc_summary.py /tmp/pmc conv_ring >> $O
+done
+cat $O

@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import caffe_rtpose_amd as r  # noqa: E402
 prec = r.PREC_FP32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else r.PREC_FP16
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-e = r.Engine(r.Config(precision=prec, frames_in_flight=1))
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+e = r.Engine(r.Config(precision=prec, frames_in_flight=batch, batch_frames=batch))
 ms, fl = e.bench_dominant_conv(iters)
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("RTP_"))
 print(f"[{tag}] dominant conv {ms * 1e3:.1f} us = {fl / ms / 1e9:.1f} TFLOP/s")
