@@ -39,7 +39,7 @@ def cpu_baseline(eng, num_scales):
             "sample": f"1 frame, {num_scales} scale(s), 656x368 COCO: conv stack {t1 - t0:.2f}s + postproc {t2 - t1:.2f}s, OpenMP fp32"}
 
 
-PMC_B2 = None  # (FETCH_SIZE KiB, WRITE_SIZE KiB) per dominant launch at batch_frames=2, from profiles/r01_dominant_conv_pmc.txt
+PMC_B2 = (7196, 2895)  # (FETCH_SIZE KiB, WRITE_SIZE KiB) per dominant launch at batch_frames=2, from profiles/r01_dominant_conv_pmc_b2.txt
 
 
 def main():

@@ -14,8 +14,8 @@ python $R/tools/timeline.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) 
 B=$(python -c "import json;print(json.load(open('$O/bench_fp16_n1.json'))['config'].get('batch_frames', 2))" 2>/dev/null || echo 2)
 : > $O/dominant_conv_pmc.txt
 echo "# rocprofv3 --kernel-trace --pmc <group> -- python tools/prof_dominant.py fp16 20 $B   (one group per pass)" >> $O/dominant_conv_pmc.txt
-for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
-  rm -rf /tmp/pmc; timeout 90 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc -- python $R/tools/prof_dominant.py fp16 20 $B > /tmp/pmc.log 2>&1
+for grp in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do  # ONE counter per pass (two TCC counters in a pass hung)
+  rm -rf /tmp/pmc; timeout 40 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc -- python $R/tools/prof_dominant.py fp16 20 $B > /tmp/pmc.log 2>&1
   python $R/tools/pmc_summary.py /tmp/pmc conv_ring >> $O/dominant_conv_pmc.txt 2>&1 || echo "group '$grp' failed" >> $O/dominant_conv_pmc.txt
 done
 tail -3 /tmp/pmc.log >> $O/dominant_conv_pmc.txt
