@@ -17,26 +17,33 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def cpu_baseline(eng, num_scales):
+MODELS = {  # name -> (model id, net_w, net_h, parts, max_peaks, nms threshold, conv GFLOP per scale-image)
+    "coco": (0, 656, 368, 18, 64, 0.05, 484.634),
+    "mpi": (1, 496, 368, 15, 20, 0.2, 361.695),
+}
+
+
+def cpu_baseline(eng, num_scales, model="coco"):
     """The CPU oracle (a port: the reference itself cannot be built here) timed on this host's cores
     on a bounded sample: ONE frame through conv stack + ImResize + NMS + connect."""
     import numpy as np
     import _oracle as orc
     import _synth
-    net = orc.Net(0)
+    mid, W, H, parts, max_peaks, thr, _ = MODELS[model]
+    net = orc.Net(mid)
     for i in range(len(net.convs)):
         w, b = eng.get_conv_weights(i)
         net.set_weights(i, w, b)
-    x = _synth.random_frame(num_scales, 368, 656, seed=1)
+    x = _synth.random_frame(num_scales, H, W, seed=1)
     t0 = time.time()
     low = net.forward(x)
     t1 = time.time()
-    res = orc.imresize(low, 656, 368, 1.0, 0.3)[0]
-    peaks = orc.nms(res, 18, 64, 0.05)
-    orc.connect(0, res, peaks, 64, 656, 368, 1280, 720)
+    res = orc.imresize(low, W, H, 1.0, 0.3)[0]
+    peaks = orc.nms(res, parts, max_peaks, thr)
+    orc.connect(mid, res, peaks, max_peaks, W, H, 1280, 720)
     t2 = time.time()
     return {"value": 1.0 / (t2 - t0), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"1 frame, {num_scales} scale(s), 656x368 COCO: conv stack {t1 - t0:.2f}s + postproc {t2 - t1:.2f}s, OpenMP fp32"}
+            "sample": f"1 frame, {num_scales} scale(s), {W}x{H} {model.upper()}: conv stack {t1 - t0:.2f}s + postproc {t2 - t1:.2f}s, OpenMP fp32"}
 
 
 PMC_B2 = (7196, 2895)  # (FETCH_SIZE KiB, WRITE_SIZE KiB) per dominant launch at batch_frames=2, from profiles/r01_dominant_conv_pmc_b2.txt
@@ -52,6 +59,7 @@ def main():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--in_flight", type=int, default=8)
     ap.add_argument("--batch_frames", type=int, default=2, help="frames whose conv stacks share one launch sequence (1 = the reference's one frame per Forward)")
+    ap.add_argument("--model", default="coco", choices=["coco", "mpi"], help="coco = BASELINE configs[1..3] (656x368); mpi = configs[4] (15 parts, 496x368)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 
@@ -71,12 +79,13 @@ def main():
 
     seed = 1
     prec = r.PREC_FP16 if args.precision == "fp16" else r.PREC_FP32
-    eng = r.Engine(r.Config(device_id=local, model=r.MODEL_COCO_18, net_w=656, net_h=368, num_scales=args.num_scales,
+    mid, W, H, _, _, _, gflop = MODELS[args.model]
+    eng = r.Engine(r.Config(device_id=local, model=mid, net_w=W, net_h=H, num_scales=args.num_scales,
                             scale_gap=args.scale_gap, precision=prec, frames_in_flight=args.in_flight, batch_frames=args.batch_frames, synthetic_seed=seed))
     # synthetic frames, resident in HBM before the timed region (u8/256-0.5 like process_and_pad_image)
     nframes = 8
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    frames = [(torch.randint(0, 256, (args.num_scales, 3, 368, 656), generator=g).float() / 256.0 - 0.5).cuda() for _ in range(nframes)]
+    frames = [(torch.randint(0, 256, (args.num_scales, 3, H, W), generator=g).float() / 256.0 - 0.5).cuda() for _ in range(nframes)]
     torch.cuda.synchronize()
 
     lat = []
@@ -125,7 +134,7 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE/WRITE_SIZE are in KiB;
         # FETCH_SIZE x2 per the guide's gfx950 correction), keyed by (num_scales, batch_frames); None = not collected
         pmc_kib = {(1, 1): (6458, 1886), (1, 2): PMC_B2}
-        fw = pmc_kib.get((args.num_scales, args.batch_frames))
+        fw = pmc_kib.get((args.num_scales, args.batch_frames)) if args.model == "coco" else None
         traffic = (2 * fw[0] + fw[1]) * 1024 if fw else None
         roof = {"bound": "mfma", "kernel": "conv_ring_kernel 7x7 128->128 (L1+L2 branch pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "ms_per_launch": ms, "launches_timed": dom_n,
@@ -133,14 +142,14 @@ def main():
         solo_ms, _ = eng.bench_dominant_conv(iters=200)   # the same kernel alone on the chip (no other frame sharing the CUs)
         roof["solo"] = {"ms_per_launch": solo_ms, "achieved": dom_flops / (solo_ms * 1e-3) / 1e12, "frac": dom_flops / (solo_ms * 1e-3) / peak}
         fps = aggregate_fps(args.steps, world, dt)
-        whole = {"achieved": fps / world * 484.634e9 * args.num_scales / 1e12, "unit": "TFLOP/s",
-                 "frac": fps / world * 484.634e9 * args.num_scales / peak}
+        whole = {"achieved": fps / world * gflop * 1e9 * args.num_scales / 1e12, "unit": "TFLOP/s",
+                 "frac": fps / world * gflop * 1e9 * args.num_scales / peak}
         out = {
-            "metric": "frames/sec (whole node) at 656x368 COCO model",
+            "metric": f"frames/sec (whole node) at {W}x{H} {args.model.upper()} model",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": f"COCO 656x368, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU in batches of {args.batch_frames}, synthetic weights",
+            "config": {"workload": f"{args.model.upper()} {W}x{H}, {args.num_scales} scale(s), conv stack+ImResize+NMS+connect, {args.in_flight} frames in flight/GPU in batches of {args.batch_frames}, synthetic weights",
                        "batch_frames": args.batch_frames, "frames_in_flight": args.in_flight, "num_scales": args.num_scales,
                        "parallelism": f"frame-sharded replicas x{world}"},
             "latency_ms": {"p50_pipelined": float(np.percentile(lat, 50) * 1e3), "p95_pipelined": float(np.percentile(lat, 95) * 1e3),
@@ -149,7 +158,7 @@ def main():
             "stage_ms_last_frame": stage, "roofline": roof, "conv_stack_whole_frame": whole,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(eng, args.num_scales)
+            out["cpu_baseline"] = cpu_baseline(eng, args.num_scales, args.model)
         print(json.dumps(out))
     eng.close()
     if dist is not None:

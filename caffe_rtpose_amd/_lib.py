@@ -52,6 +52,11 @@ SIGNATURES = {
     "rtp_submit_frame": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint64, fp]),
     "rtp_debug_preprocess": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, fp, C.POINTER(C.c_ubyte), fp]),
     "rtp_flush": (C.c_int, [vp]),
+    "rtp_decode_image": (C.c_int, [C.POINTER(C.c_ubyte), C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t, ip, ip]),
+    "rtp_codec_last_error": (C.c_char_p, []),
+    "rtp_video_open": (C.c_int, [C.c_char_p, C.POINTER(vp), ip, ip, ip]),
+    "rtp_video_read": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_size_t]),
+    "rtp_video_close": (None, [vp]),
     "rtp_post_from_lowres": (C.c_int, [vp, fp, fp, fp, ip]),
     "rtp_profile_steps": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_double), C.c_int]),
     "rtp_collect": (C.c_int, [vp, C.POINTER(C.c_uint64), fp, ip]),

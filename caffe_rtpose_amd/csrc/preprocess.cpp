@@ -162,6 +162,8 @@ int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::
   return 0;
 }
 
+extern "C" int rtp_internal_load_png_jpeg(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h);
+
 extern "C" {
 
 // rtpose.cpp:324-329: scale-to-fit, top-left anchored
@@ -264,7 +266,8 @@ int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, in
     }
     return RTP_OK;
   }
-  return RTP_EIO;  // JPEG/PNG need a codec this image does not have
+  f.close();
+  return rtp_internal_load_png_jpeg(path, out_bgr, capacity, w, h);  // codecs.cpp
 }
 
 // Procedural frame `index` of the synthetic video (BASELINE config 2: "synthetic 720p video"):

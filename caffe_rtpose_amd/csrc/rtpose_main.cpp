@@ -6,7 +6,7 @@
 //   1 writer (JSON, latency log every 30 frames)                                     :1315-1454
 // There is no collective: frames are independent.  Differences from the reference,
 // all forced by the environment: no display/camera (no GUI stack), image decoding limited to
-// PPM/BMP (no codecs), `--video synthetic:WxH:frames[:seed]` generates frames procedurally, and the
+// JPEG/PNG/PPM/BMP and Y4M / raw MJPEG (codecs.cpp), `--video synthetic:WxH:frames[:seed]` generates frames procedurally, and the
 // process exits at end of input also without --write_frames (the reference loops the video forever).
 #include <atomic>
 #include <chrono>
@@ -96,7 +96,7 @@ int parse_flags(int argc, char** argv, Flags& F) {
 
 void usage() {
   printf("rtpose.bin (MI355X engine) — flags as examples/rtpose/rtpose.cpp:\n"
-         "  --video PATH|synthetic:WxH:frames[:seed]   --image_dir DIR (ppm/bmp)   --camera N (unsupported)\n"
+         "  --video FILE.y4m|FILE.mjpeg|synthetic:WxH:frames[:seed]   --image_dir DIR (jpg/png/bmp/ppm)   --camera N (unsupported)\n"
          "  --caffeproto FILE --caffemodel FILE   | --model coco|mpi (built-in graph, synthetic weights)\n"
          "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
          "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
@@ -157,8 +157,14 @@ void producer() {
   int sw = 0, sh = 0, nframes = 0;
   unsigned long long seed = 2;
   const bool synthetic = F.video.rfind("synthetic:", 0) == 0;
+  rtp_video* vid = nullptr;
   if (synthetic) {
     if (sscanf(F.video.c_str(), "synthetic:%dx%d:%d:%llu", &sw, &sh, &nframes, &seed) < 3) { fprintf(stderr, "bad --video %s\n", F.video.c_str()); G.quit_threads = true; return; }
+  } else if (!F.video.empty()) {  // cv::VideoCapture(FLAGS_video), rtpose.cpp:402-411
+    if (rtp_video_open(F.video.c_str(), &vid, &sw, &sh, &nframes) != RTP_OK) { fprintf(stderr, "Couldn't open video file %s: %s\n", F.video.c_str(), rtp_codec_last_error()); G.quit_threads = true; G.producer_done = true; return; }
+    if (nframes < 0) nframes = 1 << 30;
+    std::vector<unsigned char> skip((size_t)sw * sh * 3);
+    for (int i = 0; i < F.start_frame; ++i) if (rtp_video_read(vid, skip.data(), skip.size()) != RTP_OK) break;  // CAP_PROP_POS_FRAMES, :411
   } else nframes = (int)G.image_list.size();
   std::vector<unsigned char> img;
   for (int fi = F.start_frame; fi < nframes && !G.quit_threads; ++fi) {
@@ -170,9 +176,15 @@ void producer() {
       img.resize((size_t)w * h * 3);
       rtp_synth_frame(img.data(), w, h, fi, seed);
       char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm;
+    } else if (vid) {
+      img.resize((size_t)w * h * 3);
+      const int rc = rtp_video_read(vid, img.data(), img.size());
+      if (rc == RTP_EAGAIN) break;  // end of the stream
+      if (rc != RTP_OK) { fprintf(stderr, "video frame %d: %s\n", fi, rtp_codec_last_error()); break; }
+      char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm;
     } else {
       const std::string& path = G.image_list[fi];
-      if (rtp_load_image(path.c_str(), nullptr, 0, &w, &h) != RTP_OK) { fprintf(stderr, "cannot decode %s (only PPM/BMP without OpenCV)\n", path.c_str()); continue; }
+      if (rtp_load_image(path.c_str(), nullptr, 0, &w, &h) != RTP_OK) { fprintf(stderr, "cannot decode %s: %s\n", path.c_str(), rtp_codec_last_error()); continue; }
       img.resize((size_t)w * h * 3);
       if (rtp_load_image(path.c_str(), img.data(), img.size(), &w, &h) != RTP_OK) continue;
       size_t sl = path.find_last_of('/'), dot = path.find_last_of('.');
@@ -196,6 +208,7 @@ void producer() {
     G.produced++;
     G.input_queue.push(std::move(fr));
   }
+  if (vid) rtp_video_close(vid);
   G.producer_done = true;
 }
 
@@ -346,7 +359,9 @@ int read_image_dir() {  // readImageDirIfFlagEnabled, rtpose.cpp:1732-1755
     const size_t dot = n.find_last_of('.');
     if (dot == std::string::npos) continue;
     const std::string ext = n.substr(dot);
-    if (ext == ".jpg" || ext == ".png" || ext == ".bmp" || ext == ".ppm") G.image_list.push_back(F.image_dir + "/" + n);
+    std::string ext_l = ext;
+    for (char& ch : ext_l) ch = (char)tolower((unsigned char)ch);
+    if (ext_l == ".jpg" || ext_l == ".jpeg" || ext_l == ".png" || ext_l == ".bmp" || ext_l == ".ppm") G.image_list.push_back(F.image_dir + "/" + n);
   }
   closedir(d);
   std::sort(G.image_list.begin(), G.image_list.end());
@@ -366,10 +381,20 @@ int main(int argc, char** argv) {
     int w = 0, h = 0;
     if (!F.image_dir.empty() && !G.image_list.empty() && rtp_load_image(G.image_list[0].c_str(), nullptr, 0, &w, &h) == RTP_OK) { DISP_W = w; DISP_H = h; }
     else if (F.video.rfind("synthetic:", 0) == 0 && sscanf(F.video.c_str(), "synthetic:%dx%d", &w, &h) == 2) { DISP_W = w; DISP_H = h; }
+    else if (!F.video.empty() && F.video.rfind("synthetic:", 0) != 0) {
+      rtp_video* v = nullptr;
+      if (rtp_video_open(F.video.c_str(), &v, &w, &h, nullptr) != RTP_OK) { fprintf(stderr, "Couldn't open video file %s: %s\n", F.video.c_str(), rtp_codec_last_error()); return 1; }
+      rtp_video_close(v);
+      DISP_W = w; DISP_H = h;
+    }
     else { fprintf(stderr, "Invalid resolution without video/images: %dx%d\n", DISP_W, DISP_H); return 1; }
   }
   if (F.video.empty() && F.image_dir.empty()) { fprintf(stderr, "Couldn't open camera %d (no capture stack in this build): use --video or --image_dir\n", F.camera); return 1; }
-  if (!F.video.empty() && F.video.rfind("synthetic:", 0) != 0) { fprintf(stderr, "Couldn't open video file %s (no codecs in this build): use synthetic:WxH:frames or --image_dir\n", F.video.c_str()); return 1; }
+  if (!F.video.empty() && F.video.rfind("synthetic:", 0) != 0) {
+    rtp_video* v = nullptr;
+    if (rtp_video_open(F.video.c_str(), &v, nullptr, nullptr, nullptr) != RTP_OK) { fprintf(stderr, "Couldn't open video file %s: %s\n", F.video.c_str(), rtp_codec_last_error()); return 1; }
+    rtp_video_close(v);
+  }
   for (const std::string* d : {&F.write_frames, &F.write_json})
     if (!d->empty() && !mkdir_p(*d)) { fprintf(stderr, "Could not write to or create directory %s\n", d->c_str()); return 1; }
   if (F.num_gpu < 1) { fprintf(stderr, "--num_gpu must be >= 1\n"); return 1; }

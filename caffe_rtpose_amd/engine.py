@@ -181,6 +181,47 @@ def read_caffemodel_layers(path):
     return out
 
 
+def decode_image(data):
+    """cv::imread(IMREAD_COLOR) of an encoded PNG / JPEG byte string -> BGR HWC u8."""
+    buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+    w, h = C.c_int(), C.c_int()
+    rc = lib.rtp_decode_image(buf, len(data), None, 0, C.byref(w), C.byref(h))
+    if rc:
+        raise RtpError(rc, lib.rtp_codec_last_error().decode())
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    rc = lib.rtp_decode_image(buf, len(data), _u8(out), out.size, C.byref(w), C.byref(h))
+    if rc:
+        raise RtpError(rc, lib.rtp_codec_last_error().decode())
+    return out
+
+
+class Video:
+    """cv::VideoCapture for Y4M / raw MJPEG files."""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        rc = lib.rtp_video_open(str(path).encode(), C.byref(self.h), C.byref(w), C.byref(h), C.byref(n))
+        if rc:
+            self.h = C.c_void_p()
+            raise RtpError(rc, lib.rtp_codec_last_error().decode())
+        self.w, self.h_, self.nframes = w.value, h.value, n.value
+
+    def read(self):
+        out = np.empty((self.h_, self.w, 3), np.uint8)
+        rc = lib.rtp_video_read(self.h, _u8(out), out.size)
+        if rc == -11:
+            return None
+        if rc:
+            raise RtpError(rc, lib.rtp_codec_last_error().decode())
+        return out
+
+    def close(self):
+        if self.h:
+            lib.rtp_video_close(self.h)
+            self.h = C.c_void_p()
+
+
 def plan_summary(cfg):
     buf = C.create_string_buffer(1 << 20)
     n = lib.rtp_plan_summary(C.byref(cfg.c), buf, len(buf))

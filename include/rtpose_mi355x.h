@@ -191,9 +191,20 @@ int rtp_warp_display(const unsigned char* bgr, int sw, int sh, unsigned char* ou
 int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h,
                          int num_scales, double start_scale, double scale_gap, float* net_input,
                          unsigned char* display_bgr, float* frame_scale);
-/* Image files decodable without OpenCV: binary PPM (P6) and 24-bit BMP -> BGR HWC.  out_bgr may be
- * NULL to query the size.  rtp_synth_frame: frame `index` of the procedural test video. */
+/* cv::imread(path, IMREAD_COLOR) (rtpose.cpp:323) without OpenCV: baseline JPEG (libjpeg's default
+ * decode arithmetic, bit-exact), PNG (zlib), binary PPM (P6), 24-bit BMP -> BGR HWC.  out_bgr may be
+ * NULL to query the size.  rtp_decode_image: the same for an encoded PNG/JPEG byte string.
+ * rtp_synth_frame: frame `index` of the procedural test video. */
 int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h);
+int rtp_decode_image(const unsigned char* bytes, size_t n, unsigned char* out_bgr, size_t capacity, int* w, int* h);
+const char* rtp_codec_last_error(void);
+/* cv::VideoCapture(path) (rtpose.cpp:402-411, 431) for the container-less formats decodable here:
+ * Y4M (YUV4MPEG2, 8 bit) and raw MJPEG streams.  nframes may be NULL; rtp_video_read returns
+ * RTP_EAGAIN at the end of the stream. */
+typedef struct rtp_video rtp_video;
+int rtp_video_open(const char* path, rtp_video** v, int* w, int* h, int* nframes);
+int rtp_video_read(rtp_video* v, unsigned char* out_bgr, size_t capacity);
+void rtp_video_close(rtp_video* v);
 int rtp_synth_frame(unsigned char* out_bgr, int w, int h, int index, uint64_t seed);
 
 /* Parse a deploy prototxt and report the graph it describes (for tests / tools). */

@@ -1,0 +1,98 @@
+"""image / video decoding without OpenCV (csrc/codecs.cpp), CPU only.
+
+JPEG is pinned bit-for-bit against Pillow's (libjpeg-turbo) decode of the same files — the library
+cv::imread runs — through the fixtures made by tools/make_codec_fixtures.py; PNG is lossless and
+pinned against the source arrays.  Y4M colour conversion is PARITY UNPINNED (stated in codecs.cpp)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "codecs")
+
+
+def _cases(ext):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*." + ext)) if os.path.exists(p[:-4] + ".npy"))
+
+
+@pytest.mark.parametrize("name", _cases("jpg"))
+def test_jpeg_decode_bit_exact_vs_libjpeg(name):
+    import caffe_rtpose_amd as r
+    want = np.load(os.path.join(GOLD, name + ".npy"))
+    data = open(os.path.join(GOLD, name + ".jpg"), "rb").read()
+    got = r.decode_image(data)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max diff {np.abs(got.astype(int) - want.astype(int)).max()}, {int((got != want).sum())} values"
+    # and through the file loader the CLI uses
+    assert np.array_equal(r.load_image(os.path.join(GOLD, name + ".jpg")), want)
+
+
+@pytest.mark.parametrize("name", _cases("png"))
+def test_png_decode_exact(name):
+    import caffe_rtpose_amd as r
+    want = np.load(os.path.join(GOLD, name + ".npy"))
+    got = r.load_image(os.path.join(GOLD, name + ".png"))
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_unsupported_and_corrupt_files_fail_with_a_message(tmp_path):
+    import caffe_rtpose_amd as r
+    with pytest.raises(r.RtpError) as ei:
+        r.decode_image(open(os.path.join(GOLD, "jprogressive.jpg"), "rb").read())
+    assert "progressive" in str(ei.value)
+    good = open(os.path.join(GOLD, "j420_q75.jpg"), "rb").read()
+    with pytest.raises(r.RtpError):
+        r.decode_image(good[: len(good) // 8])          # cut inside the headers
+    with pytest.raises(r.RtpError):
+        r.decode_image(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
+    with pytest.raises(r.RtpError):
+        r.decode_image(b"GIF89a" + b"\0" * 64)
+    # a truncated scan still decodes (libjpeg pads with zeros too): same size, no crash
+    assert r.decode_image(good[: len(good) - 40]).shape == np.load(os.path.join(GOLD, "j420_q75.npy")).shape
+    png = open(os.path.join(GOLD, "p_rgb8.png"), "rb").read()
+    with pytest.raises(r.RtpError):
+        r.decode_image(png[: len(png) - 30])
+
+
+def test_y4m_and_mjpeg_readers(tmp_path):
+    import caffe_rtpose_amd as r
+    W, H, n = 20, 12, 3
+    rs = np.random.RandomState(3)
+    frames = []
+    p = tmp_path / "clip.y4m"
+    with open(p, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420jpeg\n" % (W, H))
+        for _ in range(n):
+            y = rs.randint(16, 236, (H, W)).astype(np.uint8)
+            u = rs.randint(16, 241, (H // 2, W // 2)).astype(np.uint8)
+            v = rs.randint(16, 241, (H // 2, W // 2)).astype(np.uint8)
+            f.write(b"FRAME\n" + y.tobytes() + u.tobytes() + v.tobytes())
+            frames.append((y, u, v))
+    vid = r.Video(p)
+    assert (vid.w, vid.h_, vid.nframes) == (W, H, n)
+    for y, u, v in frames:
+        got = vid.read()
+        c = 298 * (y.astype(np.int64) - 16)
+        d = np.repeat(np.repeat(u, 2, 0), 2, 1).astype(np.int64) - 128
+        e = np.repeat(np.repeat(v, 2, 0), 2, 1).astype(np.int64) - 128
+        want = np.stack([np.clip((c + 516 * d + 128) >> 8, 0, 255), np.clip((c - 100 * d - 208 * e + 128) >> 8, 0, 255),
+                         np.clip((c + 409 * e + 128) >> 8, 0, 255)], -1).astype(np.uint8)
+        assert np.array_equal(got, want)
+    assert vid.read() is None
+    vid.close()
+    # raw MJPEG = concatenated JPEG files
+    a = open(os.path.join(GOLD, "j420_q75.jpg"), "rb").read()
+    b = open(os.path.join(GOLD, "j444_q90.jpg"), "rb").read()
+    m = tmp_path / "clip.mjpeg"
+    m.write_bytes(a + b + a)
+    vid = r.Video(m)
+    assert vid.nframes == 3
+    assert np.array_equal(vid.read(), np.load(os.path.join(GOLD, "j420_q75.npy")))
+    assert np.array_equal(vid.read(), np.load(os.path.join(GOLD, "j444_q90.npy")))
+    assert np.array_equal(vid.read(), np.load(os.path.join(GOLD, "j420_q75.npy")))
+    assert vid.read() is None
+    vid.close()
+    with pytest.raises(r.RtpError):
+        r.Video(os.path.join(GOLD, "p_rgb8.png"))

@@ -157,3 +157,53 @@ int main(int argc, char**) {
     subprocess.check_call(["g++", "-std=c++17", "-I", ROOT, "-o", str(exe), str(src), "-L", os.path.join(ROOT, "caffe_rtpose_amd"),
                            "-lrtpose_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "caffe_rtpose_amd")])
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_cli_video_file_errors():
+    p = subprocess.run([BIN, "--video", "/nonexistent/clip.y4m", "--model", "coco"], capture_output=True)
+    assert p.returncode == 1 and b"Couldn't open video file" in p.stderr
+    png = os.path.join(ROOT, "tests", "golden", "codecs", "p_rgb8.png")
+    p = subprocess.run([BIN, "--video", png, "--model", "coco"], capture_output=True)
+    assert p.returncode == 1 and b"Y4M" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_image_dir_and_video_files_match_library_path(tmp_path):
+    """--image_dir with JPEG/PNG files and --video with a raw MJPEG stream: one JSON per image stem /
+    frame number, byte-identical to decoding + submitting the same frames through the library."""
+    import shutil
+    import caffe_rtpose_amd as r
+    gold = os.path.join(ROOT, "tests", "golden", "codecs")
+    d = tmp_path / "imgs"
+    d.mkdir()
+    names = ["j420_q75.jpg", "j444_q90.jpg", "p_rgb8.png"]
+    for n in names:
+        shutil.copy(os.path.join(gold, n), d / n)
+    out = tmp_path / "js"
+    common = ["--model", "coco", "--net_resolution", "160x96", "--resolution", "320x240", "--no_frame_drops", "--no_display", "--num_gpu", "1"]
+    p = subprocess.run([BIN, "--image_dir", str(d), "--write_json", str(out)] + common, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    assert sorted(os.listdir(out)) == sorted(n.rsplit(".", 1)[0] + ".json" for n in names)
+    e = r.Engine(r.Config(net_w=160, net_h=96, disp_w=320, disp_h=240, frames_in_flight=1))
+
+    def want_json(img):
+        fs = e.submit_frame(img, tag=1)
+        _, n, joints = e.collect()
+        full = np.zeros((96, 18, 3), np.float32)
+        full[:n] = joints
+        return r.format_json(full, n, 18, fs)
+
+    for n in names:
+        assert open(out / (n.rsplit(".", 1)[0] + ".json"), "rb").read() == want_json(r.load_image(d / n)), n
+    # raw MJPEG "video": frames 0..2 -> frame%06d.json
+    clip = tmp_path / "clip.mjpeg"
+    a = open(os.path.join(gold, "j420_q75.jpg"), "rb").read()
+    clip.write_bytes(a + a + a)
+    out2 = tmp_path / "js2"
+    p = subprocess.run([BIN, "--video", str(clip), "--write_json", str(out2)] + common, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    assert sorted(os.listdir(out2)) == [f"frame{i:06d}.json" for i in range(3)]
+    w = want_json(r.load_image(os.path.join(gold, "j420_q75.jpg")))
+    for i in range(3):
+        assert open(out2 / f"frame{i:06d}.json", "rb").read() == w
+    e.close()
