@@ -167,8 +167,12 @@ constexpr int ring_wait_count(int s) {
   return n;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW>
-__global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
+// SPEC = wave specialisation: 8 waves, one producer + one consumer per SIMD.  Waves 4..7 only issue
+// the LDS-DMA (and wait for it, counted); waves 0..3 only ds_read + MFMA (+ the epilogue).  The
+// in-order VMEM issue of a wave (~50 cycles per 1 KiB piece, 3-5 pieces per tap) then no longer sits
+// in front of the same wave's MFMAs.  Same LDS image, same wait counts, one barrier per tap for all.
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvParams P) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
   constexpr int A_PW = TR::A_PW, B_PW = TR::B_PW, TM = TR::TM, TN = TR::TN;
@@ -183,7 +187,9 @@ __global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
   const int tid = threadIdx.x;
   if (P.tstamp && tid == 0) atomicMin(&P.tstamp[0], (unsigned long long)wall_clock64());
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = SPEC && wave_all >= 4;
+  const int wave = SPEC ? (wave_all & 3) : wave_all;  // consumer role / share of the DMA pieces
   const int kg = wave / (WM * WN);
   const int wrem = wave % (WM * WN);
   const int wm0 = (wrem / WN) * (BM / WM);
@@ -281,6 +287,113 @@ __global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
     }
   };
 
+  if constexpr (SPEC) {
+    int abuf = 0, st = 1, ist = 0;
+    if (producer) {
+      issue_a(0);
+      issue_a(1);
+#pragma unroll
+      for (int i = 0; i < SB; ++i) issue_b(i);
+      wait_vmcnt<(SB - 1) * B_PW>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      auto pstep = [&](auto s_tag, auto first_tag) {
+        constexpr int s = decltype(s_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (s == 0) { abuf ^= 1; issue_a(abuf ^ 1); }
+        issue_b(ist);
+        ist = (ist + 1 == SB) ? 0 : ist + 1;
+      };
+      pstep(std::integral_constant<int, 1>{}, std::true_type{});
+      pstep(std::integral_constant<int, 2>{}, std::true_type{});
+      if constexpr (KS == 7) {
+        pstep(std::integral_constant<int, 3>{}, std::true_type{});
+        pstep(std::integral_constant<int, 4>{}, std::true_type{});
+        pstep(std::integral_constant<int, 5>{}, std::true_type{});
+        pstep(std::integral_constant<int, 6>{}, std::true_type{});
+      }
+      for (int sc = 1; sc < nstrips; ++sc) {
+        pstep(std::integral_constant<int, 0>{}, std::false_type{});
+        pstep(std::integral_constant<int, 1>{}, std::false_type{});
+        pstep(std::integral_constant<int, 2>{}, std::false_type{});
+        if constexpr (KS == 7) {
+          pstep(std::integral_constant<int, 3>{}, std::false_type{});
+          pstep(std::integral_constant<int, 4>{}, std::false_type{});
+          pstep(std::integral_constant<int, 5>{}, std::false_type{});
+          pstep(std::integral_constant<int, 6>{}, std::false_type{});
+        }
+      }
+      wait_vmcnt<0>();  // the dummy tail DMAs have landed before LDS is reused by the epilogue
+      __builtin_amdgcn_s_barrier();
+      return;           // the consumers' later barriers count live waves only
+    }
+    // ---- consumers ----
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0, fa, fb);
+    auto read_one_c = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) {
+      const int gi = idx / (TM + TN), q = idx % (TM + TN);
+      const int cl = 2 * (kg * GPW + gi) + lhalf;
+      if (q < TM) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
+      else nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
+    };
+    constexpr int NMMA_C = GPW * TM * TN, NRD_C = GPW * (TM + TN);
+    auto cstep = [&](auto s_tag) {
+      constexpr int s = decltype(s_tag)::value;
+      wait_vmcnt<63>();  // lgkmcnt(0): this wave's ds_reads of the stage about to be overwritten have returned
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (s == 0) abuf ^= 1;
+      const int arow = arow_base + s;
+      const int aswz = ring_swz<CHB>(arow);
+      const unsigned char* pa = sA + abuf * TR::A_BYTES + arow * CHB;
+      const unsigned char* pb = pb_lane + st * TR::B_BYTES;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < NMMA_C; ++m) {
+        {
+          const int gi = m / (TM * TN), r = m % (TM * TN);
+          Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
+        }
+#pragma unroll
+        for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rd, pa, pb, aswz);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      st = (st + 1 == SB) ? 0 : st + 1;
+      rotate();
+    };
+    cstep(std::integral_constant<int, 1>{});
+    cstep(std::integral_constant<int, 2>{});
+    if constexpr (KS == 7) {
+      cstep(std::integral_constant<int, 3>{});
+      cstep(std::integral_constant<int, 4>{});
+      cstep(std::integral_constant<int, 5>{});
+      cstep(std::integral_constant<int, 6>{});
+    }
+    for (int sc = 1; sc < nstrips; ++sc) {
+      cstep(std::integral_constant<int, 0>{});
+      cstep(std::integral_constant<int, 1>{});
+      cstep(std::integral_constant<int, 2>{});
+      if constexpr (KS == 7) {
+        cstep(std::integral_constant<int, 3>{});
+        cstep(std::integral_constant<int, 4>{});
+        cstep(std::integral_constant<int, 5>{});
+        cstep(std::integral_constant<int, 6>{});
+      }
+    }
+    mma_all();  // last tap
+    wait_vmcnt<63>();
+    __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
+    conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
+    if (P.tstamp && tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      atomicMax(&P.tstamp[1], (unsigned long long)wall_clock64());
+    }
+    return;
+  }
   // ---- prologue ----------------------------------------------------------------------------
   issue_a(0);
   issue_a(1);
@@ -372,10 +485,19 @@ __global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams P) {
   }
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC>
+static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream);
+
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
+  if (P.spec) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true>(P, nprob, N, stream);
+  return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, false>(P, nprob, N, stream);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC>
+static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
-  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW>;
+  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC>;
   static std::atomic<unsigned> attr_mask{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -387,7 +509,7 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
   dim3 grid(P.tiles_per_img * N * (P.CoutP / BN) * nprob);
   static const char* ldsmax = getenv("RTP_RING_LDS_MAX");
   const int lds = (ldsmax && ldsmax[0] == '1') ? 160 * 1024 : TR::LDS_BYTES;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, P);
+  hipLaunchKernelGGL(kern, grid, dim3(SPEC ? 512 : 256), lds, stream, P);
   return hipGetLastError();
 }
 

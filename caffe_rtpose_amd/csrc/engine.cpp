@@ -598,8 +598,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
     P.xcdmap = (xm && xm[0] == '0') ? 0 : 1;
     static const char* sb = getenv("RTP_RING_SB");
     P.ring_sb = (sb && sb[0] == '4') ? 4 : 6;
-    static const char* ab = getenv("RTP_RING_ABLATE");
-    P.ablate = ab ? atoi(ab) : 0;
+    static const char* sp = getenv("RTP_RING_SPEC");
+    P.spec = (sp && sp[0] == '0') ? 0 : 1;  // wave-specialised ring kernels (default); 0 = every wave does both
   }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));

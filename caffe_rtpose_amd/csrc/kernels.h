@@ -48,7 +48,7 @@ struct ConvParams {
   int rotate;  // ring kernel: rotate the filter-row order per tile (speed only)
   int xcdmap;  // 1: contiguous logical range per XCD (decode_block), 0: dispatch order
   int ring_sb; // ring depth request (4 or 6) where both are instantiated
-  int ablate;  // unused (kept for ABI stability of the experiments)
+  int spec;    // ring kernel: 1 = wave-specialised variant (4 DMA waves + 4 MFMA waves)
   // optional {min start, max end} wall_clock64() slot of this launch (bench.py's in-situ kernel
   // timing: what a profiler's kernel trace reports, unlike stream events which also count the time
   // a launch queues behind other frames' kernels)
