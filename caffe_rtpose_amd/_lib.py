@@ -54,6 +54,7 @@ SIGNATURES = {
     "rtp_flush": (C.c_int, [vp]),
     "rtp_decode_image": (C.c_int, [C.POINTER(C.c_ubyte), C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t, ip, ip]),
     "rtp_codec_last_error": (C.c_char_p, []),
+    "rtp_encode_jpeg": (C.c_long, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_size_t]),
     "rtp_video_open": (C.c_int, [C.c_char_p, C.POINTER(vp), ip, ip, ip]),
     "rtp_video_read": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_size_t]),
     "rtp_video_close": (None, [vp]),

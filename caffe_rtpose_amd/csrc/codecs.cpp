@@ -600,6 +600,258 @@ bool read_file(const char* path, std::vector<unsigned char>* buf) {
 }  // namespace
 
 // =================================================================================================
+// JPEG encoder: cv::imwrite(name, img, {CV_IMWRITE_JPEG_QUALITY, q}) (rtpose.cpp:1367-1381) =
+// libjpeg's defaults: JFIF 1.01, YCbCr 4:2:0, baseline, standard Huffman tables (Annex K),
+// jccolor.c RGB->YCC tables, jcsample.c h2v2 down-sampling with alternating bias, edge replication
+// (jcprepct.c / jcsample.c) and dummy edge blocks (jccoefct.c), jfdctint.c forward DCT, jcdctmgr.c
+// rounding division.  PINNED byte-for-byte against Pillow's (libjpeg-turbo) files in tests/golden/codecs.
+// =================================================================================================
+namespace {
+
+const unsigned char kStdLumQ[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                    14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const unsigned char kStdChrQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99,
+                                    47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const unsigned char kDcLumBits[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const unsigned char kDcChrBits[17] = {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const unsigned char kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const unsigned char kAcLumBits[17] = {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const unsigned char kAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+    0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+    0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+    0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+    0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+const unsigned char kAcChrBits[17] = {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const unsigned char kAcChrVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+    0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+    0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+    0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+    0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+    0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+
+struct EncHuff { unsigned short code[256]; unsigned char size[256]; };
+void build_enc_huff(EncHuff* h, const unsigned char bits[17], const unsigned char* vals) {
+  memset(h, 0, sizeof *h);
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    for (int i = 0; i < bits[l]; ++i) { h->code[vals[k]] = (unsigned short)code++; h->size[vals[k]] = (unsigned char)l; ++k; }
+    code <<= 1;
+  }
+}
+
+struct BitWriter {
+  std::vector<unsigned char>* out;
+  uint32_t acc = 0;
+  int n = 0;
+  void put(unsigned code, int size) {
+    if (!size) return;
+    acc = (acc << size) | (code & ((1u << size) - 1));
+    n += size;
+    while (n >= 8) {
+      const unsigned char b = (unsigned char)((acc >> (n - 8)) & 0xFF);
+      out->push_back(b);
+      if (b == 0xFF) out->push_back(0);
+      n -= 8;
+    }
+  }
+  void flush() { put(0x7F, 7); acc = 0; n = 0; }  // libjpeg pads the last byte with 1-bits
+};
+
+// jfdctint.c jpeg_fdct_islow, in place on level-shifted samples; output scaled by 8
+void fdct_islow(int* data) {
+  const int CONST_BITS = 13, PASS1_BITS = 2;
+  const long F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
+             F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
+             F_2_562915447 = 20995, F_3_072711026 = 25172;
+  auto descale = [](long x, int n) { return (int)((x + (1L << (n - 1))) >> n); };
+  for (int pass = 0; pass < 2; ++pass) {
+    const int step = pass ? 8 : 1, next = pass ? 1 : 8;
+    for (int i = 0; i < 8; ++i) {
+      int* d = data + i * next;
+      const long tmp0 = d[0] + d[7 * step], tmp7 = d[0] - d[7 * step], tmp1 = d[step] + d[6 * step], tmp6 = d[step] - d[6 * step];
+      const long tmp2 = d[2 * step] + d[5 * step], tmp5 = d[2 * step] - d[5 * step], tmp3 = d[3 * step] + d[4 * step], tmp4 = d[3 * step] - d[4 * step];
+      const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+      long z1 = (tmp12 + tmp13) * F_0_541196100;
+      if (!pass) {
+        d[0] = (int)((tmp10 + tmp11) * (1L << PASS1_BITS));
+        d[4 * step] = (int)((tmp10 - tmp11) * (1L << PASS1_BITS));
+        d[2 * step] = descale(z1 + tmp13 * F_0_765366865, CONST_BITS - PASS1_BITS);
+        d[6 * step] = descale(z1 + tmp12 * (-F_1_847759065), CONST_BITS - PASS1_BITS);
+      } else {
+        d[0] = descale(tmp10 + tmp11, PASS1_BITS);
+        d[4 * step] = descale(tmp10 - tmp11, PASS1_BITS);
+        d[2 * step] = descale(z1 + tmp13 * F_0_765366865, CONST_BITS + PASS1_BITS);
+        d[6 * step] = descale(z1 + tmp12 * (-F_1_847759065), CONST_BITS + PASS1_BITS);
+      }
+      z1 = tmp4 + tmp7;
+      long z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+      const long z5 = (z3 + z4) * F_1_175875602;
+      const long t4 = tmp4 * F_0_298631336, t5 = tmp5 * F_2_053119869, t6 = tmp6 * F_3_072711026, t7 = tmp7 * F_1_501321110;
+      z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
+      z3 += z5; z4 += z5;
+      const int sh = pass ? CONST_BITS + PASS1_BITS : CONST_BITS - PASS1_BITS;
+      d[7 * step] = descale(t4 + z1 + z3, sh);
+      d[5 * step] = descale(t5 + z2 + z4, sh);
+      d[3 * step] = descale(t6 + z2 + z3, sh);
+      d[step] = descale(t7 + z1 + z4, sh);
+    }
+  }
+}
+
+inline int bit_category(int v) { int a = v < 0 ? -v : v, n = 0; while (a) { ++n; a >>= 1; } return n; }
+
+}  // namespace
+
+extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int quality, unsigned char* out, size_t capacity) {
+  if (!bgr || W < 1 || H < 1 || W > 65535 || H > 65535) return RTP_EINVAL;
+  if (quality < 1) quality = 1;
+  if (quality > 100) quality = 100;
+  const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;  // jpeg_quality_scaling
+  unsigned char qt[2][64];
+  for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < 64; ++i) {
+      long v = ((long)(t ? kStdChrQ[i] : kStdLumQ[i]) * scale + 50L) / 100L;
+      if (v <= 0) v = 1;
+      if (v > 255) v = 255;  // force_baseline
+      qt[t][i] = (unsigned char)v;
+    }
+  // ---- planes: Y at full resolution, Cb/Cr down-sampled 2x2; all padded to whole 16x16 MCUs
+  const int mcux = (W + 15) / 16, mcuy = (H + 15) / 16;
+  const int yw_blocks = (W + 7) / 8, yh_blocks = (H + 7) / 8;              // real blocks (width_in_blocks)
+  const int cw_blocks = ((W + 1) / 2 + 7) / 8, ch_blocks = ((H + 1) / 2 + 7) / 8;
+  const int YW = mcux * 16, YH = mcuy * 16, CW = mcux * 8, CH = mcuy * 8;
+  std::vector<unsigned char> Y((size_t)YW * YH), Cb((size_t)CW * CH), Cr((size_t)CW * CH);
+  {
+    // colour conversion of the real pixels (jccolor.c rgb_ycc_convert)
+    const int H2 = (H + 1) & ~1;                 // rows after padding to max_v_samp_factor (replicate the last row)
+    const int fullw = std::max(yw_blocks * 8, cw_blocks * 16);  // expand_right_edge targets
+    std::vector<unsigned char> fy((size_t)fullw * H2), fcb((size_t)fullw * H2), fcr((size_t)fullw * H2);
+    for (int y = 0; y < H2; ++y) {
+      const unsigned char* src = bgr + (size_t)std::min(y, H - 1) * W * 3;
+      for (int x = 0; x < fullw; ++x) {
+        const unsigned char* px = src + (size_t)std::min(x, W - 1) * 3;
+        const long r = px[2], g = px[1], b = px[0];
+        fy[(size_t)y * fullw + x] = (unsigned char)((19595L * r + 38470L * g + 7471L * b + 32768L) >> 16);
+        fcb[(size_t)y * fullw + x] = (unsigned char)((-11059L * r - 21709L * g + 32768L * b + (128L << 16) + 32767L) >> 16);
+        fcr[(size_t)y * fullw + x] = (unsigned char)((32768L * r - 27439L * g - 5329L * b + (128L << 16) + 32767L) >> 16);
+      }
+    }
+    // luma: copy; rows below the image replicate the last (padded) row up to the iMCU height
+    for (int y = 0; y < YH; ++y) {
+      const int sy = std::min(y, H2 - 1);
+      for (int x = 0; x < YW; ++x) Y[(size_t)y * YW + x] = fy[(size_t)sy * fullw + std::min(x, yw_blocks * 8 - 1)];
+    }
+    // chroma: h2v2_downsample with bias 1,2,1,2 along the row
+    const int crow = H2 / 2, ccol = cw_blocks * 8;
+    for (int y = 0; y < CH; ++y) {
+      const int sy = std::min(y, crow - 1);
+      for (int x = 0; x < CW; ++x) {
+        const int sx = std::min(x, ccol - 1);
+        const int bias = (sx & 1) ? 2 : 1;
+        const size_t o0 = (size_t)(2 * sy) * fullw + 2 * sx, o1 = o0 + fullw;
+        Cb[(size_t)y * CW + x] = (unsigned char)((fcb[o0] + fcb[o0 + 1] + fcb[o1] + fcb[o1 + 1] + bias) >> 2);
+        Cr[(size_t)y * CW + x] = (unsigned char)((fcr[o0] + fcr[o0 + 1] + fcr[o1] + fcr[o1 + 1] + bias) >> 2);
+      }
+    }
+  }
+  std::vector<unsigned char> o;
+  o.reserve((size_t)W * H);
+  auto put16 = [&](int v) { o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)v); };
+  o.push_back(0xFF); o.push_back(0xD8);
+  const unsigned char app0[] = {0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+  o.insert(o.end(), app0, app0 + sizeof app0);
+  for (int t = 0; t < 2; ++t) {
+    o.push_back(0xFF); o.push_back(0xDB); put16(67); o.push_back((unsigned char)t);
+    for (int i = 0; i < 64; ++i) o.push_back(qt[t][kZigzag[i]]);
+  }
+  o.push_back(0xFF); o.push_back(0xC0); put16(17); o.push_back(8); put16(H); put16(W); o.push_back(3);
+  o.push_back(1); o.push_back(0x22); o.push_back(0);
+  o.push_back(2); o.push_back(0x11); o.push_back(1);
+  o.push_back(3); o.push_back(0x11); o.push_back(1);
+  auto dht = [&](int tc_th, const unsigned char* bits, const unsigned char* vals, int nv) {
+    o.push_back(0xFF); o.push_back(0xC4); put16(2 + 1 + 16 + nv); o.push_back((unsigned char)tc_th);
+    for (int i = 1; i <= 16; ++i) o.push_back(bits[i]);
+    o.insert(o.end(), vals, vals + nv);
+  };
+  dht(0x00, kDcLumBits, kDcVals, 12);
+  dht(0x10, kAcLumBits, kAcLumVals, 162);
+  dht(0x01, kDcChrBits, kDcVals, 12);
+  dht(0x11, kAcChrBits, kAcChrVals, 162);
+  const unsigned char sos[] = {0xFF, 0xDA, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
+  o.insert(o.end(), sos, sos + sizeof sos);
+  EncHuff hdc[2], hac[2];
+  build_enc_huff(&hdc[0], kDcLumBits, kDcVals); build_enc_huff(&hac[0], kAcLumBits, kAcLumVals);
+  build_enc_huff(&hdc[1], kDcChrBits, kDcVals); build_enc_huff(&hac[1], kAcChrBits, kAcChrVals);
+  BitWriter bw;
+  bw.out = &o;
+  int pred[3] = {0, 0, 0};
+  int blk[64], prev_q0 = 0;
+  auto code_block = [&](const unsigned char* plane, int stride, int bx, int by, bool real, int comp, int tq) {
+    int q[64];
+    if (real) {
+      for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) blk[r * 8 + c] = (int)plane[(size_t)(by * 8 + r) * stride + bx * 8 + c] - 128;
+      fdct_islow(blk);
+      for (int i = 0; i < 64; ++i) {
+        const int qval = qt[tq][i] << 3;
+        int t = blk[i];
+        if (t < 0) { t = -t; t += qval >> 1; t = t >= qval ? t / qval : 0; t = -t; }
+        else { t += qval >> 1; t = t >= qval ? t / qval : 0; }
+        q[i] = t;
+      }
+    } else {  // dummy edge block: zero AC, DC of the previous block (jccoefct.c)
+      memset(q, 0, sizeof q);
+      q[0] = prev_q0;
+    }
+    prev_q0 = q[0];
+    const int hidx = comp ? 1 : 0;
+    int diff = q[0] - pred[comp];
+    pred[comp] = q[0];
+    int s = bit_category(diff);
+    bw.put(hdc[hidx].code[s], hdc[hidx].size[s]);
+    if (s) bw.put((unsigned)(diff < 0 ? diff - 1 : diff), s);
+    int run = 0;
+    for (int k = 1; k < 64; ++k) {
+      const int v = q[kZigzag[k]];
+      if (v == 0) { ++run; continue; }
+      while (run > 15) { bw.put(hac[hidx].code[0xF0], hac[hidx].size[0xF0]); run -= 16; }
+      s = bit_category(v);
+      const int sym = (run << 4) | s;
+      bw.put(hac[hidx].code[sym], hac[hidx].size[sym]);
+      bw.put((unsigned)(v < 0 ? v - 1 : v), s);
+      run = 0;
+    }
+    if (run) bw.put(hac[hidx].code[0], hac[hidx].size[0]);
+  };
+  for (int my = 0; my < mcuy; ++my)
+    for (int mx = 0; mx < mcux; ++mx) {
+      for (int by = 0; by < 2; ++by)
+        for (int bx = 0; bx < 2; ++bx) {
+          const int gx = mx * 2 + bx, gy = my * 2 + by;
+          code_block(Y.data(), YW, gx, gy, gx < yw_blocks && gy < yh_blocks, 0, 0);
+        }
+      code_block(Cb.data(), CW, mx, my, mx < cw_blocks && my < ch_blocks, 1, 1);
+      code_block(Cr.data(), CW, mx, my, mx < cw_blocks && my < ch_blocks, 2, 1);
+    }
+  bw.flush();
+  o.push_back(0xFF); o.push_back(0xD9);
+  if (out) {
+    if (capacity < o.size()) return cfail(RTP_EINVAL, "output buffer too small");
+    memcpy(out, o.data(), o.size());
+  }
+  return (long)o.size();
+}
+
+// =================================================================================================
 // Video readers
 // =================================================================================================
 struct rtp_video {

@@ -198,6 +198,10 @@ int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int
 int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h);
 int rtp_decode_image(const unsigned char* bytes, size_t n, unsigned char* out_bgr, size_t capacity, int* w, int* h);
 const char* rtp_codec_last_error(void);
+/* cv::imwrite(name, img, {CV_IMWRITE_JPEG_QUALITY, quality}) (rtpose.cpp:1367-1381): libjpeg's default
+ * baseline 4:2:0 encoder restated, byte-identical files.  Returns the size in bytes (out may be NULL
+ * to query it) or a negative RTP_E* code. */
+long rtp_encode_jpeg(const unsigned char* bgr, int w, int h, int quality, unsigned char* out, size_t capacity);
 /* cv::VideoCapture(path) (rtpose.cpp:402-411, 431) for the container-less formats decodable here:
  * Y4M (YUV4MPEG2, 8 bit) and raw MJPEG streams.  nframes may be NULL; rtp_video_read returns
  * RTP_EAGAIN at the end of the stream. */

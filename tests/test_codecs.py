@@ -96,3 +96,19 @@ def test_y4m_and_mjpeg_readers(tmp_path):
     vid.close()
     with pytest.raises(r.RtpError):
         r.Video(os.path.join(GOLD, "p_rgb8.png"))
+
+
+@pytest.mark.parametrize("ref", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "enc_*.jpgref"))))
+def test_jpeg_encoder_byte_identical_to_libjpeg(ref):
+    """cv::imwrite(.jpg, quality) = libjpeg defaults: the file must equal Pillow's (libjpeg-turbo) byte for byte."""
+    import caffe_rtpose_amd as r
+    src = np.load(os.path.join(GOLD, ref[:-7] + ".npy"))
+    q = int(ref[:-7].rsplit("_q", 1)[1])
+    want = open(os.path.join(GOLD, ref), "rb").read()
+    got = r.encode_jpeg(src, q)
+    assert got == want
+    # and our own decoder reads it back to what libjpeg would: round trip stays close to the source
+    dec = r.decode_image(got)
+    assert dec.shape == src.shape
+    if q >= 90 and src.shape[0] > 8:
+        assert np.abs(dec.astype(int) - src.astype(int)).mean() < 6.0

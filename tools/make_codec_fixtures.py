@@ -81,4 +81,11 @@ for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (
 png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 11, 9, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
 open(os.path.join(OUT, "p_rgb8_adam7.png"), "wb").write(png)
 np.save(os.path.join(OUT, "p_rgb8_adam7.npy"), c[:, :, ::-1].copy())
+# ---- JPEG encoder: source pixels (BGR) + the bytes Pillow/libjpeg-turbo writes (= cv::imwrite's defaults: 4:2:0, std tables)
+for w, h, q in [(67, 45, 98), (33, 17, 98), (16, 16, 75), (1, 1, 98), (8, 24, 50), (17, 33, 30), (40, 9, 98)]:
+    s = scene(w, h)
+    buf = io.BytesIO()
+    Image.fromarray(s).save(buf, "JPEG", quality=q)
+    np.save(os.path.join(OUT, f"enc_{w}x{h}_q{q}.npy"), s[:, :, ::-1].copy())
+    open(os.path.join(OUT, f"enc_{w}x{h}_q{q}.jpgref"), "wb").write(buf.getvalue())
 print(sorted(os.listdir(OUT)), sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)), "bytes")
