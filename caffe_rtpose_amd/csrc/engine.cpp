@@ -94,6 +94,10 @@ struct Slot {
   unsigned char* frame_host = nullptr;  // pinned staging of the raw frame
   size_t frame_cap = 0;
   unsigned char* disp_dev = nullptr;    // display-resolution u8 image
+  bool has_disp = false;                // disp_dev holds this frame's display image (rtp_submit_frame, device path)
+  unsigned char* render_dev = nullptr;  // cfg.render: display image with the pose overlay
+  unsigned char* render_host = nullptr; // pinned copy of it
+  float* render_tab = nullptr;
   uint64_t tag = 0;
   bool busy = false;
 };
@@ -719,6 +723,20 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
       if ((rc = run_post_fused(e, cx, j, sl.ev[2]))) return rc;
     }
     HIPCHK(e, hipEventRecord(sl.ev[3], sl.stream));
+    if (e->cfg.render && sl.has_disp) {  // pose overlay on the display image (renderFunctions.cu, part_to_show == 0)
+      const size_t dbytes = (size_t)e->cfg.disp_w * e->cfg.disp_h * 3;
+      if (!sl.render_dev) {
+        HIPCHK(e, hipMalloc((void**)&sl.render_dev, dbytes));
+        HIPCHK(e, hipHostMalloc((void**)&sl.render_host, dbytes, hipHostMallocDefault));
+        HIPCHK(e, hipMalloc((void**)&sl.render_tab, render_tab_floats(RTP_MAX_PEOPLE) * sizeof(float)));
+      }
+      RenderParams rp;
+      rp.src = sl.disp_dev; rp.dst = sl.render_dev; rp.w = e->cfg.disp_w; rp.h = e->cfg.disp_h;
+      rp.poses = sl.joints; rp.num_people = sl.num_people; rp.tab = sl.render_tab;
+      rp.model = e->model; rp.googly = 0; rp.max_people = RTP_MAX_PEOPLE;
+      HIPCHK(e, launch_render(rp, sl.stream));
+      HIPCHK(e, hipMemcpyAsync(sl.render_host, sl.render_dev, dbytes, hipMemcpyDeviceToHost, sl.stream));
+    }
     HIPCHK(e, hipMemcpyAsync(sl.host_out + 4, sl.joints, jbytes, hipMemcpyDeviceToHost, sl.stream));
     HIPCHK(e, hipMemcpyAsync(sl.host_out, sl.num_people, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
     HIPCHK(e, hipEventRecord(sl.ev[4], sl.stream));
@@ -779,9 +797,10 @@ void free_ctx(Ctx& cx) {
   for (Slot& sl : cx.slot) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     void* dptrs[] = {sl.resized, sl.peaks, sl.strip_count, sl.strip_list, sl.cand_score, sl.cand_ij, sl.cand_count, sl.cand_blk, sl.conn, sl.conn_score,
-                     sl.conn_count, sl.joints, sl.num_people, sl.frame_dev, sl.disp_dev};
+                     sl.conn_count, sl.joints, sl.num_people, sl.frame_dev, sl.disp_dev, sl.render_dev, sl.render_tab};
     for (void* p : dptrs) if (p) (void)hipFree(p);
     if (sl.frame_host) (void)hipHostFree(sl.frame_host);
+    if (sl.render_host) (void)hipHostFree(sl.render_host);
     if (sl.host_out) (void)hipHostFree(sl.host_out);
     for (int i = 0; i < 5; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1096,12 +1115,14 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if (e->B == 1) {  // no staging copy: the conv stack reads the caller's tensor
     cx.slot[0].tag = tag;
     cx.slot[0].busy = true;
+    cx.slot[0].has_disp = false;
     cx.filled = 1;
     e->fifo.push_back(ci * 64);
     e->open_ctx = -1;
     return launch_batch(e, cx, 1, d_in);
   }
   HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, d_in, bytes, hipMemcpyDeviceToDevice, cx.stream));
+  cx.slot[sj].has_disp = false;
   return commit_slot(e, ci, sj, tag);
 }
 
@@ -1114,6 +1135,7 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   memcpy((char*)cx.host_in + sj * bytes, h_in, bytes);
   HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, cx.stream));
+  cx.slot[sj].has_disp = false;
   return commit_slot(e, ci, sj, tag);
 }
 
@@ -1125,6 +1147,7 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint
   if ((rc = use_device(e))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
+  cx.slot[sj].has_disp = e->gpu_prep_ok;
   if (e->gpu_prep_ok) {
     if ((rc = enqueue_preprocess(e, cx, sj, bgr, w, h, frame_scale))) return rc;
   } else {  // a pyramid level would have to be enlarged: host restatement (linear fallback) + H2D
@@ -1173,7 +1196,15 @@ static void stage_ms(rtp_engine* e, Ctx& cx, Slot& sl) {
   }
 }
 
-int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) {
+static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_people, unsigned char* rendered, bool want_render);
+int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) { return collect_impl(e, tag, joints, num_people, nullptr, false); }
+// rtp_collect + the display-resolution frame with the pose overlay (the image the reference hands to
+// cv::imwrite under --write_frames --no_text, rtpose.cpp:1179-1199, 1286-1293).  Needs
+// rtp_config.render = 1 and frames submitted with rtp_submit_frame.
+int rtp_collect_rendered(rtp_engine* e, uint64_t* tag, float* joints, int* num_people, unsigned char* display_bgr) {
+  return collect_impl(e, tag, joints, num_people, display_bgr, true);
+}
+static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_people, unsigned char* rendered, bool want_render) {
   if (!e) return RTP_EINVAL;
   if (e->fifo.empty()) return fail(e, RTP_EAGAIN, "nothing in flight");
   int rc;
@@ -1199,6 +1230,11 @@ int rtp_collect(rtp_engine* e, uint64_t* tag, float* joints, int* num_people) {
   if (n > RTP_MAX_PEOPLE) n = RTP_MAX_PEOPLE;
   if (num_people) *num_people = n;
   if (joints) memcpy(joints, sl.host_out + 4, (size_t)n * e->num_parts * 3 * sizeof(float));
+  if (want_render) {
+    if (!e->cfg.render) return fail(e, RTP_EINVAL, "rtp_collect_rendered needs rtp_config.render = 1");
+    if (!sl.has_disp || !sl.render_host) return fail(e, RTP_EINVAL, "no display image for this frame: submit it with rtp_submit_frame (device pre-processing)");
+    if (rendered) memcpy(rendered, sl.render_host, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3);
+  }
   return RTP_OK;
 }
 

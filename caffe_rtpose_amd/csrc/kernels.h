@@ -105,6 +105,21 @@ hipError_t launch_area_pad(const unsigned char* disp, int dw, int dh, const Area
                            hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
+// Renderer (row 8f-3): render.hip
+// ---------------------------------------------------------------------------------------
+struct RenderParams {
+  const unsigned char* src;  // display image, u8 BGR HWC (device)
+  unsigned char* dst;        // rendered image, same layout
+  int w, h;
+  const float* poses;        // joints [max_people][num_parts][3], display coordinates (device)
+  const int* num_people;     // device
+  float* tab;                // scratch, render_tab_floats(max_people)
+  int model, googly, max_people;
+};
+hipError_t launch_render(const RenderParams& p, hipStream_t stream);
+size_t render_tab_floats(int max_people);
+
+// ---------------------------------------------------------------------------------------
 // Post-processing (bit-exact restatements of the reference's CUDA kernels / host loop).
 // ---------------------------------------------------------------------------------------
 struct ResizeParams {

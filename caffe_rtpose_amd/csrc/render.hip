@@ -1,0 +1,201 @@
+// render.hip — SURVEY.md §8(f)-3: the reference's pose overlay (renderFunctions.cu:124-240 MPI,
+// :394-636 COCO; part_to_show == 0) on the display-resolution frame, followed by
+// postProcessFrame's float -> u8 conversion (rtpose.cpp:1286-1293).  Oracle: orc_render_pose.
+//
+// MI355X-first shape, not the reference's: the reference evaluates atan2f/sinf/cosf of every limb
+// of every person in EVERY pixel thread and keeps a float canvas (11 MB at 720p) that travels
+// H2D and back.  Here a one-workgroup prep kernel computes the per-person box / scale and the
+// per-limb ellipse frame once (same inputs -> the same values every pixel would have computed), and
+// the pixel kernel reads the u8 display image the pre-processing kernels already left on the
+// device, blends in registers with the reference's arithmetic (C's usual conversions: several MPI
+// blends are double) and writes u8.  Built with the BITEXACT flags (no FMA contraction).
+#include "kernels.h"
+
+namespace rtp {
+
+__constant__ int kRColorCoco[18 * 3] = {255, 0, 0, 255, 85, 0, 255, 170, 0, 255, 255, 0, 170, 255, 0, 85, 255, 0, 0, 255, 0, 0, 255, 85,
+                                        0, 255, 170, 0, 255, 255, 0, 170, 255, 0, 85, 255, 0, 0, 255, 85, 0, 255, 170, 0, 255, 255, 0, 255,
+                                        255, 0, 170, 255, 0, 85};
+__constant__ int kRColorMpi[9 * 3] = {255, 0, 0, 255, 170, 0, 170, 255, 0, 0, 255, 0, 0, 255, 170, 0, 170, 255, 0, 0, 255, 170, 0, 255, 255, 0, 170};
+__constant__ int kRLimbCoco[17 * 2] = {1, 2, 1, 5, 2, 3, 3, 4, 5, 6, 6, 7, 1, 8, 8, 9, 9, 10, 1, 11, 11, 12, 12, 13, 1, 0, 0, 14, 14, 16, 0, 15, 15, 17};
+__constant__ int kRLimbMpi[9 * 2] = {0, 1, 2, 3, 3, 4, 5, 6, 6, 7, 8, 9, 9, 10, 11, 12, 12, 13};
+
+// table layout (floats): [0] = number of people; person p at 8 + p * RTAB_PERSON:
+//   [0..3] box min x, min y, max x, max y   [4] scale   [8 + l*6 ..] limb l: valid, x_p, y_p, sine, cosine, a_sqrt
+#define RTAB_PERSON (8 + 17 * 6)
+
+__global__ __launch_bounds__(128) void render_prep_kernel(RenderParams p) {
+  int n = *p.num_people;
+  n = n < 0 ? 0 : (n > p.max_people ? p.max_people : n);
+  if (threadIdx.x == 0) p.tab[0] = (float)n;
+  const bool coco = p.model == 0;
+  const int NP = coco ? 18 : 15, NL = coco ? 17 : 9;
+  const float threshold = coco ? 0.01f : 0.0f;
+  const int* limb = coco ? kRLimbCoco : kRLimbMpi;
+  for (int q = threadIdx.x; q < n; q += blockDim.x) {
+    float* t = p.tab + 8 + (size_t)q * RTAB_PERSON;
+    const float* ps = p.poses + (size_t)q * NP * 3;
+    float mnx = p.w, mny = p.h, mxx = 0, mxy = 0, sx = 1.f;
+    if (coco) {
+      for (int part = 0; part < NP; part++) {
+        const float x = ps[part * 3], y = ps[part * 3 + 1], z = ps[part * 3 + 2];
+        if (z > threshold) {
+          if (x < mnx) mnx = x;
+          if (x > mxx) mxx = x;
+          if (y < mny) mny = y;
+          if (y > mxy) mxy = y;
+        }
+      }
+      sx = mxx - mnx;
+      const float sy = mxy - mny;
+      sx = (sx + sy) / 2.0;
+      if (sx < 200) {
+        sx = sx / 200;
+        if (sx < 0.33) sx = 0.33;
+      } else {
+        sx = 1.0;
+      }
+      mxx += 50; mxy += 50; mnx -= 50; mny -= 50;
+    }
+    t[0] = mnx; t[1] = mny; t[2] = mxx; t[3] = mxy; t[4] = sx;
+    for (int l = 0; l < NL; l++) {
+      const int a = limb[2 * l], b = limb[2 * l + 1];
+      const float x_a = ps[a * 3], x_b = ps[b * 3], y_a = ps[a * 3 + 1], y_b = ps[b * 3 + 1];
+      float* o = t + 8 + l * 6;
+      if (ps[a * 3 + 2] > threshold && ps[b * 3 + 2] > threshold) {
+        const float x_p = (x_a + x_b) / 2, y_p = (y_a + y_b) / 2;
+        const float angle = atan2f(y_b - y_a, x_b - x_a);
+        o[0] = 1.f; o[1] = x_p; o[2] = y_p; o[3] = sinf(angle); o[4] = cosf(angle);
+        o[5] = (x_a - x_p) * (x_a - x_p) + (y_a - y_p) * (y_a - y_p);
+      } else {
+        o[0] = 0.f;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void render_pose_kernel(RenderParams p) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= p.w || y >= p.h) return;
+  const unsigned char* s = p.src + ((size_t)y * p.w + x) * 3;
+  float b = s[0], g = s[1], r = s[2];
+  const int n = (int)p.tab[0];
+  const bool coco = p.model == 0;
+  if (coco) {
+    const float threshold = 0.01f;
+    const float radius = 2 * p.h / 200.0f;
+    const float stickwidth = p.h / 120.0f;
+    for (int q = 0; q < n; q++) {
+      const float* t = p.tab + 8 + (size_t)q * RTAB_PERSON;
+      if (x > t[2] || x < t[0] || y > t[3] || y < t[1]) continue;
+      const float sc = t[4];
+      const float* ps = p.poses + (size_t)q * 18 * 3;
+      for (int l = 0; l < 17; l++) {
+        const float* o = t + 8 + l * 6;
+        if (o[0] == 0.f) continue;
+        const float b_sqrt = sc * sc * stickwidth * stickwidth;
+        const float alpha = 0.5;
+        const float x_p = o[1], y_p = o[2], sine = o[3], cosine = o[4], a_sqrt = o[5];
+        const float A = cosine * (x - x_p) + sine * (y - y_p);
+        const float B = sine * (x - x_p) - cosine * (y - y_p);
+        const float judge = A * A / a_sqrt + B * B / b_sqrt;
+        if (judge >= 0 && judge <= 1) {
+          b = (1 - alpha) * b + alpha * kRColorCoco[l * 3 + 2];
+          g = (1 - alpha) * g + alpha * kRColorCoco[l * 3 + 1];
+          r = (1 - alpha) * r + alpha * kRColorCoco[l * 3 + 0];
+        }
+      }
+      for (int i = 0; i < 18; i++) {
+        const float local_x = ps[i * 3], local_y = ps[i * 3 + 1], value = ps[i * 3 + 2];
+        if (value > threshold) {
+          const float dist2 = (x - local_x) * (x - local_x) + (y - local_y) * (y - local_y);
+          float minr2 = 0;
+          float maxr2 = sc * sc * radius * radius;
+          float alpha = 0.6;
+          float cx = kRColorCoco[i * 3 + 0], cy = kRColorCoco[i * 3 + 1], cz = kRColorCoco[i * 3 + 2];
+          if (p.googly && (i == 14 || i == 15)) {
+            maxr2 = sc * sc * 2.5 * 2.5 * radius * radius;
+            minr2 = sc * sc * (2.5 * radius - 2) * (2.5 * radius - 2);
+            alpha = 0.9;
+            cx = 0; cy = 0; cz = 0;
+            if (dist2 <= maxr2) {
+              if (dist2 <= minr2) { cx = 255; cy = 255; cz = 255; }
+              if (dist2 <= minr2 * 0.6) {
+                const float dist3 = (x - 4 - local_x) * (x - 4 - local_x) + (y - local_y + 4) * (y - local_y + 4);
+                if (dist3 > 3.75 * 3.75) { cx = 0; cy = 0; cz = 0; }
+              }
+              b = (1 - alpha) * b + alpha * cz;
+              g = (1 - alpha) * g + alpha * cy;
+              r = (1 - alpha) * r + alpha * cx;
+            }
+          } else if (dist2 >= minr2 && dist2 <= maxr2) {
+            b = (1 - alpha) * b + alpha * cz;
+            g = (1 - alpha) * g + alpha * cy;
+            r = (1 - alpha) * r + alpha * cx;
+          }
+        }
+      }
+    }
+  } else {
+    const float threshold = 0.0f;
+    const float radius = 3 * p.h / 200.0f;
+    const float stickwidth = p.h / 60.0f;
+    for (int q = 0; q < n; q++) {
+      const float* t = p.tab + 8 + (size_t)q * RTAB_PERSON;
+      const float* ps = p.poses + (size_t)q * 15 * 3;
+      for (int l = 0; l < 9; l++) {
+        const float* o = t + 8 + l * 6;
+        if (o[0] == 0.f) continue;
+        float b_sqrt = stickwidth * stickwidth;
+        const float alpha = 0.6;
+        const float x_p = o[1], y_p = o[2], sine = o[3], cosine = o[4];
+        float a_sqrt = o[5];
+        if (l == 0) {
+          a_sqrt *= 1.2;
+          b_sqrt = a_sqrt;
+        }
+        const float A = cosine * (x - x_p) + sine * (y - y_p);
+        const float B = sine * (x - x_p) - cosine * (y - y_p);
+        const float judge = A * A / a_sqrt + B * B / b_sqrt;
+        float minV = 0;
+        if (l == 0) minV = 0.8;
+        if (judge >= minV && judge <= 1) {
+          b = (1 - alpha) * b + alpha * kRColorMpi[l * 3 + 2];
+          g = (1 - alpha) * g + alpha * kRColorMpi[l * 3 + 1];
+          r = (1 - alpha) * r + alpha * kRColorMpi[l * 3];
+        }
+      }
+      for (int i = 0; i < 15; i++) {
+        const float px = ps[i * 3], py = ps[i * 3 + 1], value = ps[i * 3 + 2];
+        if (value > threshold) {
+          if ((x - px) * (x - px) + (y - py) * (y - py) <= radius * radius) {
+            b = 0.6 * b + 0.4 * kRColorMpi[(i % 9) * 3 + 2];
+            g = 0.6 * g + 0.4 * kRColorMpi[(i % 9) * 3 + 1];
+            r = 0.6 * r + 0.4 * kRColorMpi[(i % 9) * 3];
+          }
+        }
+      }
+    }
+  }
+  unsigned char* o = p.dst + ((size_t)y * p.w + x) * 3;
+  const float v3[3] = {b, g, r};
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    int value = int(v3[c] + 0.5);
+    value = value < 0 ? 0 : (value > 255 ? 255 : value);
+    o[c] = (unsigned char)value;
+  }
+}
+
+hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(render_prep_kernel, dim3(1), dim3(128), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(render_pose_kernel, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+size_t render_tab_floats(int max_people) { return 8 + (size_t)max_people * RTAB_PERSON; }
+
+}  // namespace rtp

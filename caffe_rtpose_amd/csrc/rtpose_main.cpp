@@ -125,6 +125,7 @@ template <typename T> class BlockingQueue {
 struct Frame {
   std::vector<float> data;         // net input (only with --host_preprocess)
   std::vector<unsigned char> image;  // decoded u8 BGR frame (default: pre-processing runs on the GPU)
+  std::vector<unsigned char> rendered;  // --write_frames: display-resolution frame with the pose overlay
   int img_w = 0, img_h = 0;
   double commit_time = 0, preprocessed_time = 0, gpu_fetched_time = 0, gpu_computed_time = 0, buffer_start_time = 0, buffer_end_time = 0;
   int index = 0, numPeople = 0, video_frame_number = 0;
@@ -226,6 +227,7 @@ void worker(int device, int* status) {
   cfg.precision = F.precision == "fp32" ? RTP_PREC_FP32 : RTP_PREC_FP16;
   cfg.frames_in_flight = F.frames_in_flight;
   cfg.batch_frames = F.batch_frames;
+  cfg.render = F.write_frames.empty() ? 0 : 1;
   rtp_engine* e = nullptr;
   if (rtp_engine_create(&cfg, &e) != RTP_OK) {
     fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));
@@ -244,7 +246,9 @@ void worker(int device, int* status) {
     int n = 0;
     Frame fr = std::move(inflight.front());
     inflight.pop_front();
-    const int rc = rtp_collect(e, &tag, joints.data(), &n);
+    if (!F.write_frames.empty()) fr.rendered.resize((size_t)DISP_W * DISP_H * 3);
+    const int rc = F.write_frames.empty() ? rtp_collect(e, &tag, joints.data(), &n)
+                                          : rtp_collect_rendered(e, &tag, joints.data(), &n, fr.rendered.data());
     if (rc != RTP_OK) { fprintf(stderr, "GPU %d frame %d: %s\n", device, fr.index, rtp_last_error(e)); n = 0; }
     fr.numPeople = n;
     fr.joints.assign(joints.begin(), joints.begin() + (size_t)n * num_parts * 3);
@@ -336,6 +340,17 @@ void writer(std::atomic<bool>* reorder_done) {
       if (n >= 0) { std::ofstream fs(fname, std::ios::binary); fs.write(buf.data(), n); }
       else fprintf(stderr, "JSON buffer too small for frame %d\n", fr.index);
     }
+    if (!F.write_frames.empty() && !fr.rendered.empty()) {  // cv::imwrite(fname, wrap_frame, {JPEG_QUALITY, 98}), rtpose.cpp:1367-1381
+      char fname[1024];
+      if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.jpg", F.write_frames.c_str(), fr.video_frame_number);
+      else snprintf(fname, sizeof fname, "%s/%s.jpg", F.write_frames.c_str(), fr.stem.c_str());
+      std::vector<unsigned char> jpg((size_t)DISP_W * DISP_H * 4 + 4096);
+      const long n = rtp_encode_jpeg(fr.rendered.data(), DISP_W, DISP_H, 98, jpg.data(), jpg.size());
+      if (n > 0) {
+        std::ofstream fs(fname, std::ios::binary);
+        fs.write((const char*)jpg.data(), n);
+      } else fprintf(stderr, "JPEG encode failed for frame %d\n", fr.index);
+    }
     G.finished++;
     counter++;
     if (counter % 30 == 0) {  // rtpose.cpp:1421-1441
@@ -398,6 +413,7 @@ int main(int argc, char** argv) {
   for (const std::string* d : {&F.write_frames, &F.write_json})
     if (!d->empty() && !mkdir_p(*d)) { fprintf(stderr, "Could not write to or create directory %s\n", d->c_str()); return 1; }
   if (F.num_gpu < 1) { fprintf(stderr, "--num_gpu must be >= 1\n"); return 1; }
+  if (!F.write_frames.empty() && F.host_preprocess) { fprintf(stderr, "--write_frames needs the device pre-processing path (drop --host_preprocess)\n"); return 1; }
 
   const double t0 = wall();
   std::vector<std::thread> workers;

@@ -314,6 +314,14 @@ class Engine:
         self._chk(lib.rtp_post_from_lowres(self.h, _f(lowres), _f(peaks), _f(joints), C.byref(n)))
         return peaks, joints[: n.value].copy(), n.value
 
+    def collect_rendered(self):
+        tag = C.c_uint64()
+        n = C.c_int()
+        joints = np.zeros((MAX_PEOPLE, self.num_parts, 3), np.float32)
+        img = np.empty((self.cfg.c.disp_h, self.cfg.c.disp_w, 3), np.uint8)
+        self._chk(lib.rtp_collect_rendered(self.h, C.byref(tag), _f(joints), C.byref(n), _u8(img)))
+        return tag.value, n.value, joints[: n.value].copy(), img
+
     def flush(self):
         self._chk(lib.rtp_flush(self.h))
 

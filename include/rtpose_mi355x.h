@@ -67,6 +67,8 @@ typedef struct rtp_config {
                             * B*num_scales images (bigger tiles fill the 256 CUs), then post-      *
                             * processes each frame on its own stream.  Per-frame results do not    *
                             * depend on B.  ceil(frames_in_flight / B) batches are in flight.       */
+  int render;              /* 1: also draw the pose overlay on the display image (render_pose_*,   *
+                            * renderFunctions.cu; part_to_show == 0) for rtp_collect_rendered        */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
@@ -113,6 +115,11 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr_host, int w, int h,
 /* Parity tap for the device pre-processing alone. */
 int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr_host, int w, int h, float* net_input_host,
                          unsigned char* display_bgr_host, float* frame_scale);
+
+/* rtp_collect + the display-resolution u8 BGR frame with the pose overlay: the image the reference
+ * passes to cv::imwrite under --write_frames (rtpose.cpp:1179-1199 render, :1286-1293 float -> u8),
+ * without the cv::putText overlays (= --no_text).  Needs rtp_config.render = 1 and rtp_submit_frame. */
+int rtp_collect_rendered(rtp_engine* e, uint64_t* tag, float* joints_host, int* num_people, unsigned char* display_bgr_host);
 
 /* Launch a partially filled batch now (batch_frames > 1: end of stream or a latency-sensitive
  * caller).  rtp_collect does this by itself when the oldest frame sits in an unlaunched batch. */

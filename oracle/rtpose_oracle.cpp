@@ -804,3 +804,171 @@ ORC_API int orc_num_threads() {
   return 1;
 #endif
 }
+
+// ---------------------------------------------------------------------------------------
+// Renderer: render_pose_coco_parts / render_pose_29parts, the part_to_show == 0
+// overlays (renderFunctions.cu:394-636 / :124-240), on the float canvas the producer makes with
+// process_and_pad_image(normalize = 0) (rtpose.cpp:349, 500), followed by postProcessFrame's
+// float -> u8 conversion `int(v + 0.5)` clamped (rtpose.cpp:1286-1293).  Thresholds 0.01 (COCO,
+// :993) and 0.0 (MPI, :339); the googly-eyes branch is the `g` key toggle (off by default).
+// Text overlays (cv::putText with wall-clock dependent numbers) are not part of this: it is the
+// image the reference writes with --no_text.  Arithmetic follows C's usual conversions at every
+// operation (several MPI blends are evaluated in double).  PARITY UNPINNED: the reference's own
+// numbers come from CUDA's atan2f/sinf/cosf.
+// in/out: u8 BGR HWC (display resolution); poses: [num_people][num_parts][3] in display coordinates.
+// ---------------------------------------------------------------------------------------
+static const int kRenderColorCoco[18 * 3] = {255, 0, 0, 255, 85, 0, 255, 170, 0, 255, 255, 0, 170, 255, 0, 85, 255, 0, 0, 255, 0, 0, 255, 85,
+                                             0, 255, 170, 0, 255, 255, 0, 170, 255, 0, 85, 255, 0, 0, 255, 85, 0, 255, 170, 0, 255, 255, 0, 255,
+                                             255, 0, 170, 255, 0, 85};
+static const int kRenderColorMpi[9 * 3] = {255, 0, 0, 255, 170, 0, 170, 255, 0, 0, 255, 0, 0, 255, 170, 0, 170, 255, 0, 0, 255, 170, 0, 255, 255, 0, 170};
+static const int kRenderLimbCoco[17 * 2] = {1, 2, 1, 5, 2, 3, 3, 4, 5, 6, 6, 7, 1, 8, 8, 9, 9, 10, 1, 11, 11, 12, 12, 13, 1, 0, 0, 14, 14, 16, 0, 15, 15, 17};
+static const int kRenderLimbMpi[9 * 2] = {0, 1, 2, 3, 3, 4, 5, 6, 6, 7, 8, 9, 9, 10, 11, 12, 12, 13};
+
+ORC_API int orc_render_pose(int model, const unsigned char* in_bgr, int w, int h, const float* poses, int num_people, int googly,
+                            unsigned char* out_bgr) {
+  if (num_people > 96) num_people = 96;
+  const int NP = model == 0 ? 18 : 15;
+  std::vector<float> mins_x(num_people), mins_y(num_people), maxs_x(num_people), maxs_y(num_people), scalef(num_people, 1.f);
+  if (model == 0) {
+    const float threshold = 0.01f;
+    for (int p = 0; p < num_people; p++) {
+      mins_x[p] = w; mins_y[p] = h; maxs_x[p] = 0; maxs_y[p] = 0;
+      for (int part = 0; part < NP; part++) {
+        const float x = poses[p * NP * 3 + part * 3], y = poses[p * NP * 3 + part * 3 + 1], z = poses[p * NP * 3 + part * 3 + 2];
+        if (z > threshold) {
+          if (x < mins_x[p]) mins_x[p] = x;
+          if (x > maxs_x[p]) maxs_x[p] = x;
+          if (y < mins_y[p]) mins_y[p] = y;
+          if (y > maxs_y[p]) maxs_y[p] = y;
+        }
+      }
+      float sx = maxs_x[p] - mins_x[p];
+      const float sy = maxs_y[p] - mins_y[p];
+      sx = (sx + sy) / 2.0;
+      if (sx < 200) {
+        sx = sx / 200;
+        if (sx < 0.33) sx = 0.33;
+      } else {
+        sx = 1.0;
+      }
+      scalef[p] = sx;
+      maxs_x[p] += 50; maxs_y[p] += 50; mins_x[p] -= 50; mins_y[p] -= 50;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float b = in_bgr[(y * w + x) * 3], g = in_bgr[(y * w + x) * 3 + 1], r = in_bgr[(y * w + x) * 3 + 2];
+      if (model == 0) {
+        const float threshold = 0.01f;
+        const float radius = 2 * h / 200.0f;
+        const float stickwidth = h / 120.0f;
+        for (int p = 0; p < num_people; p++) {
+          if (x > maxs_x[p] || x < mins_x[p] || y > maxs_y[p] || y < mins_y[p]) continue;
+          for (int l = 0; l < 17; l++) {
+            const float b_sqrt = scalef[p] * scalef[p] * stickwidth * stickwidth;
+            const float alpha = 0.5;
+            const int part_a = kRenderLimbCoco[2 * l], part_b = kRenderLimbCoco[2 * l + 1];
+            const float x_a = poses[p * NP * 3 + part_a * 3], x_b = poses[p * NP * 3 + part_b * 3];
+            const float y_a = poses[p * NP * 3 + part_a * 3 + 1], y_b = poses[p * NP * 3 + part_b * 3 + 1];
+            const float value_a = poses[p * NP * 3 + part_a * 3 + 2], value_b = poses[p * NP * 3 + part_b * 3 + 2];
+            if (value_a > threshold && value_b > threshold) {
+              const float x_p = (x_a + x_b) / 2, y_p = (y_a + y_b) / 2;
+              const float angle = atan2f(y_b - y_a, x_b - x_a);
+              const float sine = sinf(angle), cosine = cosf(angle);
+              const float a_sqrt = (x_a - x_p) * (x_a - x_p) + (y_a - y_p) * (y_a - y_p);
+              const float A = cosine * (x - x_p) + sine * (y - y_p);
+              const float B = sine * (x - x_p) - cosine * (y - y_p);
+              const float judge = A * A / a_sqrt + B * B / b_sqrt;
+              if (judge >= 0 && judge <= 1) {
+                b = (1 - alpha) * b + alpha * kRenderColorCoco[(l % 18) * 3 + 2];
+                g = (1 - alpha) * g + alpha * kRenderColorCoco[(l % 18) * 3 + 1];
+                r = (1 - alpha) * r + alpha * kRenderColorCoco[(l % 18) * 3 + 0];
+              }
+            }
+          }
+          for (int i = 0; i < NP; i++) {
+            const float local_x = poses[p * NP * 3 + i * 3], local_y = poses[p * NP * 3 + i * 3 + 1], value = poses[p * NP * 3 + i * 3 + 2];
+            if (value > threshold) {
+              const float dist2 = (x - local_x) * (x - local_x) + (y - local_y) * (y - local_y);
+              float minr2 = 0;
+              float maxr2 = scalef[p] * scalef[p] * radius * radius;
+              float alpha = 0.6;
+              float cx = kRenderColorCoco[(i % 18) * 3 + 0], cy = kRenderColorCoco[(i % 18) * 3 + 1], cz = kRenderColorCoco[(i % 18) * 3 + 2];
+              if (googly && (i == 14 || i == 15)) {
+                maxr2 = scalef[p] * scalef[p] * 2.5 * 2.5 * radius * radius;
+                minr2 = scalef[p] * scalef[p] * (2.5 * radius - 2) * (2.5 * radius - 2);
+                alpha = 0.9;
+                cx = 0; cy = 0; cz = 0;
+                if (dist2 <= maxr2) {
+                  if (dist2 <= minr2) { cx = 255; cy = 255; cz = 255; }
+                  if (dist2 <= minr2 * 0.6) {
+                    const float dist3 = (x - 4 - local_x) * (x - 4 - local_x) + (y - local_y + 4) * (y - local_y + 4);
+                    if (dist3 > 3.75 * 3.75) { cx = 0; cy = 0; cz = 0; }
+                  }
+                  b = (1 - alpha) * b + alpha * cz;
+                  g = (1 - alpha) * g + alpha * cy;
+                  r = (1 - alpha) * r + alpha * cx;
+                }
+              } else if (dist2 >= minr2 && dist2 <= maxr2) {
+                b = (1 - alpha) * b + alpha * cz;
+                g = (1 - alpha) * g + alpha * cy;
+                r = (1 - alpha) * r + alpha * cx;
+              }
+            }
+          }
+        }
+      } else {
+        const float threshold = 0.0f;
+        const float radius = 3 * h / 200.0f;
+        const float stickwidth = h / 60.0f;
+        for (int p = 0; p < num_people; p++) {
+          for (int l = 0; l < 9; l++) {
+            float b_sqrt = stickwidth * stickwidth;
+            const float alpha = 0.6;
+            const int part_a = kRenderLimbMpi[2 * l], part_b = kRenderLimbMpi[2 * l + 1];
+            const float x_a = poses[p * NP * 3 + part_a * 3], x_b = poses[p * NP * 3 + part_b * 3];
+            const float y_a = poses[p * NP * 3 + part_a * 3 + 1], y_b = poses[p * NP * 3 + part_b * 3 + 1];
+            const float value_a = poses[p * NP * 3 + part_a * 3 + 2], value_b = poses[p * NP * 3 + part_b * 3 + 2];
+            if (value_a > threshold && value_b > threshold) {
+              const float x_p = (x_a + x_b) / 2, y_p = (y_a + y_b) / 2;
+              const float angle = atan2f(y_b - y_a, x_b - x_a);
+              const float sine = sinf(angle), cosine = cosf(angle);
+              float a_sqrt = (x_a - x_p) * (x_a - x_p) + (y_a - y_p) * (y_a - y_p);
+              if (l == 0) {
+                a_sqrt *= 1.2;
+                b_sqrt = a_sqrt;
+              }
+              const float A = cosine * (x - x_p) + sine * (y - y_p);
+              const float B = sine * (x - x_p) - cosine * (y - y_p);
+              const float judge = A * A / a_sqrt + B * B / b_sqrt;
+              float minV = 0;
+              if (l == 0) minV = 0.8;
+              if (judge >= minV && judge <= 1) {
+                b = (1 - alpha) * b + alpha * kRenderColorMpi[l * 3 + 2];
+                g = (1 - alpha) * g + alpha * kRenderColorMpi[l * 3 + 1];
+                r = (1 - alpha) * r + alpha * kRenderColorMpi[l * 3];
+              }
+            }
+          }
+          for (int i = 0; i < NP; i++) {
+            const float px = poses[p * NP * 3 + i * 3], py = poses[p * NP * 3 + i * 3 + 1], value = poses[p * NP * 3 + i * 3 + 2];
+            if (value > threshold) {
+              if ((x - px) * (x - px) + (y - py) * (y - py) <= radius * radius) {
+                b = 0.6 * b + 0.4 * kRenderColorMpi[(i % 9) * 3 + 2];
+                g = 0.6 * g + 0.4 * kRenderColorMpi[(i % 9) * 3 + 1];
+                r = 0.6 * r + 0.4 * kRenderColorMpi[(i % 9) * 3];
+              }
+            }
+          }
+        }
+      }
+      const float v3[3] = {b, g, r};
+      for (int c = 0; c < 3; c++) {
+        int value = int(v3[c] + 0.5);
+        value = value < 0 ? 0 : (value > 255 ? 255 : value);
+        out_bgr[(y * w + x) * 3 + c] = (unsigned char)value;
+      }
+    }
+  return 0;
+}

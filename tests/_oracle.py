@@ -112,6 +112,18 @@ def connect(model, resized, peaks, max_peaks, net_w, net_h, disp_w, disp_h, thr=
     return cnt, joints
 
 
+def render_pose(model, bgr, joints, num_people, googly=0):
+    img = np.ascontiguousarray(bgr, np.uint8)
+    j = np.ascontiguousarray(joints, np.float32).reshape(-1)
+    if j.size == 0:
+        j = np.zeros(3, np.float32)
+    out = np.empty_like(img)
+    rc = lib().orc_render_pose(model, img.ctypes.data_as(C.POINTER(C.c_ubyte)), img.shape[1], img.shape[0], _f(j), num_people, googly,
+                               out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert rc == 0
+    return out
+
+
 def write_json(joints, num_people, num_parts, frame_scale):
     buf = C.create_string_buffer(1 << 20)
     j = np.ascontiguousarray(joints, np.float32)

@@ -513,3 +513,38 @@ def test_fused_postproc_repeatable_while_another_engine_keeps_the_chip_busy():
     assert bad == 0, f"{bad} of 250 taps differed under load"
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------------------
+# renderer (§8f-3): pose overlay on the display image == oracle restatement of renderFunctions.cu
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,W,H", [(0, 320, 176), (1, 256, 192)])
+def test_rendered_frame_matches_oracle(model, W, H):
+    """The device evaluates atan2f/sinf/cosf with ocml, the oracle with glibc: a last-ulp difference
+    can flip the `judge <= 1` test of a pixel ON an ellipse boundary, so the comparison allows a few
+    boundary pixels (< 0.05%) and requires everything else to be identical."""
+    import caffe_rtpose_amd as r
+    dw, dh = 640, 360
+    e = _engine(model=model, net_w=W, net_h=H, disp_w=dw, disp_h=dh, frames_in_flight=2, render=1)
+    thr = orc.default_thresholds(model)
+    e.set_thresholds(thr["nms_threshold"], thr["inter_threshold"], thr["inter_min_above"], 2, 0.05)   # keep more "people" of the noise maps
+    total = 0
+    for i in range(3):
+        img = r.synth_frame(800, 600, i, seed=13)
+        _, disp, _ = r.preprocess_frame(img, dw, dh, W, H, 1, 1.0, 0.3)
+        e.submit_frame(img, tag=i)
+        tag, n, joints, got = e.collect_rendered()
+        assert tag == i
+        want = orc.render_pose(model, disp, joints, n)
+        bad = (got != want).any(-1)
+        assert bad.mean() < 5e-4, f"{int(bad.sum())} pixels differ"
+        if n == 0:
+            assert np.array_equal(got, disp)
+        total += n
+    assert total > 0, "the test frames produced no people: nothing was drawn"
+    # frames submitted as float tensors have no display image
+    x = r.preprocess_frame(r.synth_frame(800, 600, 0, seed=13), dw, dh, W, H, 1, 1.0, 0.3)[0]
+    e.submit(x, tag=9)
+    with pytest.raises(r.RtpError):
+        e.collect_rendered()
+    e.close()

@@ -79,3 +79,23 @@ def test_connect_recovers_planted_people_and_json():
         assert np.allclose(got, exp, atol=12)
         js = orc.write_json(joints, n, tabs[0], 1.0)
         assert js.count(b"joints") == 3
+
+
+def test_render_pose_oracle_sanity():
+    """orc_render_pose (renderFunctions.cu restatement): no people -> the image comes back unchanged
+    (float -> u8 of integers); people change pixels only inside their boxes; COCO and MPI tables."""
+    rs = np.random.RandomState(2)
+    img = rs.randint(0, 256, (120, 160, 3)).astype(np.uint8)
+    for model, NP in ((0, 18), (1, 15)):
+        assert np.array_equal(orc.render_pose(model, img, np.zeros((0, NP, 3), np.float32), 0), img)
+        pose = np.zeros((1, NP, 3), np.float32)
+        pose[0, :, 0] = 40 + rs.rand(NP) * 60
+        pose[0, :, 1] = 30 + rs.rand(NP) * 50
+        pose[0, :, 2] = 0.8
+        out = orc.render_pose(model, img, pose, 1)
+        changed = np.argwhere((out != img).any(-1))
+        assert len(changed) > 100
+        assert changed[:, 1].min() >= 40 - 60 and changed[:, 1].max() <= 100 + 60 and changed[:, 0].min() >= 0
+        # parts below the threshold draw nothing
+        pose[0, :, 2] = 0.0
+        assert np.array_equal(orc.render_pose(model, img, pose, 1), img)

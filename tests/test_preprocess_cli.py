@@ -207,3 +207,25 @@ def test_cli_image_dir_and_video_files_match_library_path(tmp_path):
     for i in range(3):
         assert open(out2 / f"frame{i:06d}.json", "rb").read() == w
     e.close()
+
+
+@pytest.mark.gpu
+def test_cli_write_frames_jpeg_equals_library_render(tmp_path):
+    """--write_frames: frame%06d.jpg = cv::imwrite(quality 98) of the rendered display frame, byte for byte
+    what the library path produces (render + rtp_encode_jpeg), and decodable."""
+    import caffe_rtpose_amd as r
+    out = tmp_path / "frames"
+    p = subprocess.run([BIN, "--video", "synthetic:640x480:3:5", "--model", "coco", "--net_resolution", "160x96", "--resolution", "320x240",
+                        "--write_frames", str(out), "--no_frame_drops", "--no_display", "--num_gpu", "1"], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    assert sorted(os.listdir(out)) == [f"frame{i:06d}.jpg" for i in range(3)]
+    e = r.Engine(r.Config(net_w=160, net_h=96, disp_w=320, disp_h=240, frames_in_flight=1, render=1))
+    for i in range(3):
+        e.submit_frame(r.synth_frame(640, 480, i, seed=5), tag=i)
+        _, n, joints, img = e.collect_rendered()
+        data = open(out / f"frame{i:06d}.jpg", "rb").read()
+        assert data == r.encode_jpeg(img, 98)
+        assert r.decode_image(data).shape == (240, 320, 3)
+    e.close()
+    p = subprocess.run([BIN, "--video", "synthetic:64x48:1", "--model", "coco", "--write_frames", str(tmp_path / "x"), "--host_preprocess"], capture_output=True)
+    assert p.returncode == 1 and b"--write_frames needs" in p.stderr
