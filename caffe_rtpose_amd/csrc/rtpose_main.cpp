@@ -134,8 +134,12 @@ struct Frame {
   std::vector<float> joints;
 };
 
+struct EncodeJob { std::string path; std::vector<unsigned char> bgr; };
+
 struct Global {
   BlockingQueue<Frame> input_queue, output_queue, output_queue_ordered;
+  BlockingQueue<EncodeJob> encode_queue;  // --write_frames: JPEG encoding is spread over a few threads (files are independent)
+  std::atomic<bool> encode_done{false};
   std::priority_queue<int, std::vector<int>, std::greater<int>> dropped_index;
   std::mutex mutex;
   std::atomic<bool> quit_threads{false};
@@ -320,6 +324,24 @@ void reorderer(std::atomic<bool>* workers_done) {
   while (!buffer.empty()) { emit(buffer.top()); buffer.pop(); }
 }
 
+// ---- JPEG encoders for --write_frames ------------------------------------------------------------------
+void encoder() {
+  std::vector<unsigned char> jpg((size_t)DISP_W * DISP_H * 4 + 4096);
+  while (true) {
+    EncodeJob job;
+    if (!G.encode_queue.try_pop(&job)) {
+      if (G.encode_done.load() && G.encode_queue.size() == 0) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(500));
+      continue;
+    }
+    const long n = rtp_encode_jpeg(job.bgr.data(), DISP_W, DISP_H, 98, jpg.data(), jpg.size());
+    if (n > 0) {
+      std::ofstream fs(job.path, std::ios::binary);
+      fs.write((const char*)jpg.data(), n);
+    } else fprintf(stderr, "JPEG encode failed for %s\n", job.path.c_str());
+  }
+}
+
 // ---- writer (displayFrame, rtpose.cpp:1315-1454) -------------------------------------------------------
 void writer(std::atomic<bool>* reorder_done) {
   int counter = 1;
@@ -344,12 +366,8 @@ void writer(std::atomic<bool>* reorder_done) {
       char fname[1024];
       if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.jpg", F.write_frames.c_str(), fr.video_frame_number);
       else snprintf(fname, sizeof fname, "%s/%s.jpg", F.write_frames.c_str(), fr.stem.c_str());
-      std::vector<unsigned char> jpg((size_t)DISP_W * DISP_H * 4 + 4096);
-      const long n = rtp_encode_jpeg(fr.rendered.data(), DISP_W, DISP_H, 98, jpg.data(), jpg.size());
-      if (n > 0) {
-        std::ofstream fs(fname, std::ios::binary);
-        fs.write((const char*)jpg.data(), n);
-      } else fprintf(stderr, "JPEG encode failed for frame %d\n", fr.index);
+      while (G.encode_queue.size() > 32) std::this_thread::sleep_for(std::chrono::milliseconds(1));  // back-pressure on the encoders
+      G.encode_queue.push(EncodeJob{fname, std::move(fr.rendered)});
     }
     G.finished++;
     counter++;
@@ -421,12 +439,16 @@ int main(int argc, char** argv) {
   for (int g = 0; g < F.num_gpu; ++g) workers.emplace_back(worker, g + F.start_device, &status[g]);
   std::atomic<bool> workers_done{false}, reorder_done{false};
   std::thread prod(producer), reo(reorderer, &workers_done), wr(writer, &reorder_done);
+  std::vector<std::thread> encoders;
+  if (!F.write_frames.empty()) for (int i = 0; i < 8; ++i) encoders.emplace_back(encoder);
   prod.join();
   for (auto& t : workers) t.join();
   workers_done = true;
   reo.join();
   reorder_done = true;
   wr.join();
+  G.encode_done = true;
+  for (auto& t : encoders) t.join();
   int rc = 0;
   for (int s : status) rc |= s;
   const double dt = wall() - t0;
