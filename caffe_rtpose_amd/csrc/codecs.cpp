@@ -323,6 +323,7 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
         if (comps[i].h < 1 || comps[i].h > 4 || comps[i].v < 1 || comps[i].v > 4 || comps[i].tq > 3) return cfail(RTP_EIO, "JPEG: bad SOF");
       }
       have_sof = true;
+      if (!out) { *ow_ = W; *oh_ = H; return RTP_OK; }  // size query: the frame header is enough
     } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
       return cfail(RTP_EINVAL, m == 0xC2 ? "JPEG: progressive files are not supported (baseline only)" : "JPEG: this coding process is not supported (baseline only)");
     } else if (m == 0xDD) {
