@@ -113,8 +113,6 @@ struct Ctx {
   std::vector<Slot> slot;
   int filled = 0;        // frames staged in the open batch
   bool launched = false;
-  std::vector<hipEvent_t> dom_a, dom_b;  // around every dominant-class conv launch (when timing is on)
-  int dom_used = 0;
 };
 
 }  // namespace
@@ -622,7 +620,6 @@ bool is_dominant_class(const rtp_engine* e, const Step& s) {
 
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg) {
   const std::vector<PoolOp>& pools = e->pools;
-  cx.dom_used = 0;
   auto geom_n = [&](int level) { Geom g = e->geom[level]; g.N = nimg; return g; };
   for (auto& s : e->steps) {
     if (s.type == 0) {
@@ -809,8 +806,6 @@ void free_ctx(Ctx& cx) {
   for (void* p : dptrs) if (p) (void)hipFree(p);
   if (cx.host_in) (void)hipHostFree(cx.host_in);
   for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
-  for (auto ev : cx.dom_a) (void)hipEventDestroy(ev);
-  for (auto ev : cx.dom_b) (void)hipEventDestroy(ev);
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
   cx = Ctx();
 }
