@@ -1,13 +1,14 @@
 // codecs.cpp — SURVEY.md §8(f)-2: the reference reads frames with cv::imread / cv::VideoCapture
 // (rtpose.cpp:323, 402-411, 431); OpenCV is absent here, so the decoders it would have used are
 // restated for the formats the CLI accepts:
-//   JPEG  baseline / extended sequential Huffman, 8 bit, 1 or 3 components (4:4:4, 4:2:2, 4:2:0,
+//   JPEG  Huffman sequential (baseline / extended, single- or multi-scan) AND progressive (SOF2: DC/AC
+//         first + refinement scans, EOB runs), 8 bit, 1 or 3 components (4:4:4, 4:2:2, 4:2:0,
 //         4:4:0), restart intervals.  The arithmetic is libjpeg(-turbo)'s DEFAULT decode path —
 //         what cv::imread and PIL both run —: dequantise, jidctint.c `jpeg_idct_islow`
 //         (CONST_BITS 13, PASS1_BITS 2), jdsample.c fancy ("triangle") up-sampling h2v1 / h2v2 /
 //         h1v2 when the down-sampled width > 2 (else replication), jdcolor.c YCbCr->RGB tables
 //         (SCALEBITS 16).  PINNED bit-for-bit against PIL's (libjpeg-turbo) decode of the fixtures in
-//         tests/golden/codecs (tools/make_codec_fixtures.py).  Progressive / arithmetic / 12-bit /
+//         tests/golden/codecs (tools/make_codec_fixtures.py).  Arithmetic-coded / lossless / 12-bit /
 //         CMYK files are rejected with a message.
 //   PNG   all colour types and bit depths, Adam7, through zlib's inflate (the one library
 //         dependency; libz ships with the ROCm image); alpha stripped, 16 bit -> high byte,
@@ -185,6 +186,7 @@ struct JComp {
   int bw = 0, bh = 0;          // blocks per row / column (padded to whole MCUs)
   int dw = 0, dh = 0;          // down-sampled size in samples (ceil)
   int pred = 0;
+  std::vector<short> coef;           // bw*bh blocks of 64 coefficients (natural order, not dequantised)
   std::vector<unsigned char> plane;  // bw*8 x bh*8
 };
 
@@ -269,7 +271,8 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
   std::vector<JComp> comps;
   int W = 0, H = 0, restart = 0;
   int adobe_transform = -1;
-  bool have_sof = false;
+  bool have_sof = false, progressive = false, geometry_done = false;
+  int hmax = 1, vmax = 1, mcux = 0, mcuy = 0, scans_done = 0;
   size_t pos = 2;
   auto u16 = [&](size_t o) { return (d[o] << 8) | d[o + 1]; };
   while (pos + 4 <= n) {
@@ -309,7 +312,8 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
         build_huff(tc ? &hac[th] : &hdc[th], bits, s + o, cnt);
         o += cnt;
       }
-    } else if (m == 0xC0 || m == 0xC1) {  // SOF0/1
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {  // SOF0/1 sequential, SOF2 progressive
+      progressive = m == 0xC2;
       if (s[0] != 8) return cfail(RTP_EINVAL, "JPEG: only 8-bit samples are supported");
       H = u16(pos + 3); W = u16(pos + 5);
       const int nc = s[5];
@@ -324,16 +328,17 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       }
       have_sof = true;
       if (!out) { *ow_ = W; *oh_ = H; return RTP_OK; }  // size query: the frame header is enough
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      return cfail(RTP_EINVAL, m == 0xC2 ? "JPEG: progressive files are not supported (baseline only)" : "JPEG: this coding process is not supported (baseline only)");
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      return cfail(RTP_EINVAL, "JPEG: this coding process is not supported (Huffman sequential and progressive only)");
     } else if (m == 0xDD) {
       restart = u16(pos + 2);
     } else if (m == 0xEE && sl >= 12 && !memcmp(s, "Adobe", 5)) {
       adobe_transform = s[11];
-    } else if (m == 0xDA) {  // SOS
+    } else if (m == 0xDA) {  // SOS: one scan into the coefficient buffers
       if (!have_sof) return cfail(RTP_EIO, "JPEG: SOS before SOF");
       const int ns = s[0];
-      if (ns != (int)comps.size()) return cfail(RTP_EINVAL, "JPEG: multi-scan (non-interleaved) files are not supported");
+      if (ns < 1 || ns > (int)comps.size() || sl < 1 + 2 * ns + 3) return cfail(RTP_EIO, "JPEG: bad SOS");
+      JComp* sc[4];
       for (int i = 0; i < ns; ++i) {
         const int cid = s[1 + 2 * i];
         JComp* c = nullptr;
@@ -341,61 +346,176 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
         if (!c) return cfail(RTP_EIO, "JPEG: SOS names an unknown component");
         c->td = s[2 + 2 * i] >> 4;
         c->ta = s[2 + 2 * i] & 15;
-        if (c->td > 3 || c->ta > 3 || !hdc[c->td].set || !hac[c->ta].set || !qset[c->tq]) return cfail(RTP_EIO, "JPEG: missing table");
+        if (c->td > 3 || c->ta > 3) return cfail(RTP_EIO, "JPEG: bad table selector");
+        sc[i] = c;
+      }
+      const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      if (!progressive && (Ss != 0 || Se != 63 || Ah || Al)) return cfail(RTP_EIO, "JPEG: spectral selection in a sequential file");
+      if (progressive && (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13)) return cfail(RTP_EIO, "JPEG: bad progressive scan parameters");
+      for (int i = 0; i < ns; ++i) {
+        if ((Ss == 0 && !Ah && !hdc[sc[i]->td].set) || (Se > 0 && !hac[sc[i]->ta].set)) return cfail(RTP_EIO, "JPEG: missing Huffman table");
       }
       pos += len;
-      // ---- entropy-coded segment ----
-      int hmax = 1, vmax = 1;
-      for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
-      if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }  // a single-component scan is never interleaved
-      const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
-      for (auto& c : comps) {
-        c.bw = mcux * c.h; c.bh = mcuy * c.v;
-        c.dw = (W * c.h + hmax - 1) / hmax; c.dh = (H * c.v + vmax - 1) / vmax;
-        c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
-        c.pred = 0;
+      if (!geometry_done) {
+        hmax = 1; vmax = 1;
+        for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+        if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }  // a single-component image is never interleaved
+        mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+        for (auto& c : comps) {
+          c.bw = mcux * c.h; c.bh = mcuy * c.v;
+          c.dw = (W * c.h + hmax - 1) / hmax; c.dh = (H * c.v + vmax - 1) / vmax;
+          c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+        }
+        geometry_done = true;
       }
+      for (int i = 0; i < ns; ++i) sc[i]->pred = 0;
       BitReader br;
       br.p = d + pos; br.end = d + n;
-      int coef[64];
-      int until_restart = restart;
-      for (int my = 0; my < mcuy; ++my)
-        for (int mx = 0; mx < mcux; ++mx) {
-          if (restart && until_restart == 0) {
-            // byte-align, expect RSTn
-            br.align_reset();
-            while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
-            if (br.p + 1 < br.end) br.p += 2;
-            for (auto& c : comps) c.pred = 0;
-            until_restart = restart;
+      int eobrun = 0;
+      // one block of scan data for component c at block (bx, by)
+      auto decode_block = [&](JComp& c, int bx, int by) -> int {
+        short* blk = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+        if (!progressive) {
+          int s0 = huff_decode(br, hdc[c.td]);
+          if (s0 < 0 || s0 > 15) return cfail(RTP_EIO, "JPEG: corrupt DC code");
+          if (s0) c.pred += extend(br.get(s0), s0);
+          blk[0] = (short)c.pred;
+          for (int k = 1; k < 64;) {
+            const int rs = huff_decode(br, hac[c.ta]);
+            if (rs < 0) return cfail(RTP_EIO, "JPEG: corrupt AC code");
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+              if (r == 15) { k += 16; continue; }
+              break;  // EOB
+            }
+            k += r;
+            if (k > 63) return cfail(RTP_EIO, "JPEG: corrupt AC run");
+            blk[kZigzag[k]] = (short)extend(br.get(sz), sz);
+            ++k;
           }
-          for (auto& c : comps)
-            for (int by = 0; by < c.v; ++by)
-              for (int bx = 0; bx < c.h; ++bx) {
-                memset(coef, 0, sizeof coef);
-                const uint16_t* q = qt[c.tq];
-                int s0 = huff_decode(br, hdc[c.td]);
-                if (s0 < 0 || s0 > 15) return cfail(RTP_EIO, "JPEG: corrupt DC code");
-                if (s0) c.pred += extend(br.get(s0), s0);
-                coef[0] = c.pred * q[0];
-                for (int k = 1; k < 64;) {
-                  const int rs = huff_decode(br, hac[c.ta]);
-                  if (rs < 0) return cfail(RTP_EIO, "JPEG: corrupt AC code");
-                  const int r = rs >> 4, sz = rs & 15;
-                  if (sz == 0) {
-                    if (r == 15) { k += 16; continue; }
-                    break;  // EOB
-                  }
-                  k += r;
-                  if (k > 63) return cfail(RTP_EIO, "JPEG: corrupt AC run");
-                  coef[kZigzag[k]] = extend(br.get(sz), sz) * q[k];
-                  ++k;
-                }
-                unsigned char* o = c.plane.data() + ((size_t)(my * c.v + by) * 8) * (c.bw * 8) + (size_t)(mx * c.h + bx) * 8;
-                idct_islow(coef, o, c.bw * 8);
-              }
-          if (restart) --until_restart;
+          return RTP_OK;
         }
+        if (Ss == 0) {  // DC scan (ITU T.81 G.1.2.1)
+          if (Ah == 0) {
+            int s0 = huff_decode(br, hdc[c.td]);
+            if (s0 < 0 || s0 > 15) return cfail(RTP_EIO, "JPEG: corrupt DC code");
+            if (s0) c.pred += extend(br.get(s0), s0);
+            blk[0] = (short)(c.pred * (1 << Al));
+          } else if (br.get(1)) blk[0] |= (short)(1 << Al);
+          return RTP_OK;
+        }
+        if (Ah == 0) {  // AC first pass (G.1.2.2)
+          if (eobrun > 0) { --eobrun; return RTP_OK; }
+          for (int k = Ss; k <= Se;) {
+            const int rs = huff_decode(br, hac[c.ta]);
+            if (rs < 0) return cfail(RTP_EIO, "JPEG: corrupt AC code");
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+              if (r < 15) {
+                eobrun = (1 << r) - 1;
+                if (r) eobrun += br.get(r);
+                break;
+              }
+              k += 16;
+              continue;
+            }
+            k += r;
+            if (k > 63) return cfail(RTP_EIO, "JPEG: corrupt AC run");
+            blk[kZigzag[k]] = (short)(extend(br.get(sz), sz) * (1 << Al));
+            ++k;
+          }
+          return RTP_OK;
+        }
+        // AC refinement (G.1.2.3; jdphuff.c decode_mcu_AC_refine)
+        const int p1 = 1 << Al, m1 = -(1 << Al);
+        int k = Ss;
+        if (eobrun == 0) {
+          for (; k <= Se; ++k) {
+            const int rs = huff_decode(br, hac[c.ta]);
+            if (rs < 0) return cfail(RTP_EIO, "JPEG: corrupt AC code");
+            int r = rs >> 4;
+            const int sz = rs & 15;
+            int value = 0;
+            if (sz) {
+              value = br.get(1) ? p1 : m1;
+            } else if (r != 15) {
+              eobrun = 1 << r;
+              if (r) eobrun += br.get(r);
+              break;
+            }
+            do {
+              short* cp = blk + kZigzag[k];
+              if (*cp != 0) {
+                if (br.get(1) && (*cp & p1) == 0) *cp = (short)(*cp + (*cp >= 0 ? p1 : m1));
+              } else if (--r < 0) break;
+              ++k;
+            } while (k <= Se);
+            if (sz && k <= Se) blk[kZigzag[k]] = (short)value;
+          }
+        }
+        if (eobrun > 0) {
+          for (; k <= Se; ++k) {
+            short* cp = blk + kZigzag[k];
+            if (*cp != 0 && br.get(1) && (*cp & p1) == 0) *cp = (short)(*cp + (*cp >= 0 ? p1 : m1));
+          }
+          --eobrun;
+        }
+        return RTP_OK;
+      };
+      auto do_restart = [&]() {
+        br.align_reset();
+        while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+        if (br.p + 1 < br.end) br.p += 2;
+        for (int i = 0; i < ns; ++i) sc[i]->pred = 0;
+        eobrun = 0;
+      };
+      int until_restart = restart;
+      if (ns == 1) {  // non-interleaved: the component's own blocks in raster order (A.2.2)
+        JComp& c = *sc[0];
+        const int nbx = (c.dw + 7) / 8, nby = (c.dh + 7) / 8;
+        for (int by = 0; by < nby; ++by)
+          for (int bx = 0; bx < nbx; ++bx) {
+            if (restart && until_restart == 0) { do_restart(); until_restart = restart; }
+            const int rc = decode_block(c, bx, by);
+            if (rc) return rc;
+            if (restart) --until_restart;
+          }
+      } else {
+        for (int my = 0; my < mcuy; ++my)
+          for (int mx = 0; mx < mcux; ++mx) {
+            if (restart && until_restart == 0) { do_restart(); until_restart = restart; }
+            for (int i = 0; i < ns; ++i)
+              for (int by = 0; by < sc[i]->v; ++by)
+                for (int bx = 0; bx < sc[i]->h; ++bx) {
+                  const int rc = decode_block(*sc[i], mx * sc[i]->h + bx, my * sc[i]->v + by);
+                  if (rc) return rc;
+                }
+            if (restart) --until_restart;
+          }
+      }
+      // continue after the entropy-coded segment: the next marker (the reader stopped in front of it)
+      pos = (size_t)(br.p - d);
+      while (pos + 1 < n && !(d[pos] == 0xFF && d[pos + 1] != 0x00 && !(d[pos + 1] >= 0xD0 && d[pos + 1] <= 0xD7))) ++pos;
+      scans_done++;
+      continue;
+    }
+    pos += len;
+  }
+  if (!scans_done) return cfail(RTP_EIO, "JPEG: no scan found");
+  {
+    {
+      // ---- coefficients -> samples: dequantise + IDCT of every block ----
+      for (auto& c : comps) {
+        if (!qset[c.tq]) return cfail(RTP_EIO, "JPEG: missing quantisation table");
+        c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+        int coef[64];
+        for (int by = 0; by < c.bh; ++by)
+          for (int bx = 0; bx < c.bw; ++bx) {
+            const short* blk = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+            for (int k = 0; k < 64; ++k) coef[kZigzag[k]] = blk[kZigzag[k]] * qt[c.tq][k];
+            idct_islow(coef, c.plane.data() + ((size_t)by * 8) * (c.bw * 8) + (size_t)bx * 8, c.bw * 8);
+          }
+      }
       // ---- up-sample + colour ----
       *ow_ = W; *oh_ = H;
       if (!out) return RTP_OK;
@@ -442,9 +562,7 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       }
       return RTP_OK;
     }
-    pos += len;
   }
-  return cfail(RTP_EIO, "JPEG: no scan found");
 }
 
 // =================================================================================================

@@ -198,8 +198,8 @@ int rtp_warp_display(const unsigned char* bgr, int sw, int sh, unsigned char* ou
 int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h,
                          int num_scales, double start_scale, double scale_gap, float* net_input,
                          unsigned char* display_bgr, float* frame_scale);
-/* cv::imread(path, IMREAD_COLOR) (rtpose.cpp:323) without OpenCV: baseline JPEG (libjpeg's default
- * decode arithmetic, bit-exact), PNG (zlib), binary PPM (P6), 24-bit BMP -> BGR HWC.  out_bgr may be
+/* cv::imread(path, IMREAD_COLOR) (rtpose.cpp:323) without OpenCV: baseline and progressive JPEG
+ * (libjpeg's default decode arithmetic, bit-exact), PNG (zlib), binary PPM (P6), 24-bit BMP -> BGR HWC.  out_bgr may be
  * NULL to query the size.  rtp_decode_image: the same for an encoded PNG/JPEG byte string.
  * rtp_synth_frame: frame `index` of the procedural test video. */
 int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h);

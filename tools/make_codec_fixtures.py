@@ -45,8 +45,15 @@ save_jpeg("j420_16x16", scene(16, 16), quality=95, subsampling=2)
 buf = io.BytesIO(); Image.fromarray(a[:, :, 0]).save(buf, "JPEG", quality=88); d = buf.getvalue()
 open(os.path.join(OUT, "jgray_q88.jpg"), "wb").write(d)
 np.save(os.path.join(OUT, "jgray_q88.npy"), np.repeat(np.asarray(Image.open(io.BytesIO(d)).convert("L"))[:, :, None], 3, 2))
-buf = io.BytesIO(); Image.fromarray(a).save(buf, "JPEG", quality=80, progressive=True)
-open(os.path.join(OUT, "jprogressive.jpg"), "wb").write(buf.getvalue())   # must be rejected with a message
+# progressive (SOF2): DC/AC first and refinement scans, EOB runs
+save_jpeg("jprog444_q80", a, quality=80, subsampling=0, progressive=True)
+save_jpeg("jprog420_q75", a, quality=75, subsampling=2, progressive=True)
+save_jpeg("jprog422_q92", scene(50, 33), quality=92, subsampling=1, progressive=True)
+save_jpeg("jprog420_tiny", scene(5, 3), quality=80, subsampling=2, progressive=True)
+save_jpeg("jprog420_rst", scene(40, 40), quality=80, subsampling=2, progressive=True, restart_marker_blocks=3)
+buf = io.BytesIO(); Image.fromarray(a[:, :, 1]).save(buf, "JPEG", quality=85, progressive=True); d = buf.getvalue()
+open(os.path.join(OUT, "jproggray_q85.jpg"), "wb").write(d)
+np.save(os.path.join(OUT, "jproggray_q85.npy"), np.repeat(np.asarray(Image.open(io.BytesIO(d)).convert("L"))[:, :, None], 3, 2))
 
 # ---- PNG ----
 def save_png(name, im, expect_bgr, **kw):
