@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import caffe_rtpose_amd as r  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+N = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1
 prec = r.PREC_FP32 if (len(sys.argv) > 3 and sys.argv[3] == "fp32") else r.PREC_FP16
 cfg = r.Config(precision=prec, num_scales=N, scale_gap=0.15, frames_in_flight=B, batch_frames=B)
 lines = [l for l in r.plan_summary(cfg).splitlines() if l.startswith("step")]
