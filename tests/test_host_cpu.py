@@ -306,7 +306,7 @@ def test_stdsort_replica_matches_libstdcxx(tmp_path):
 
 
 def test_bit_exact_kernels_contain_no_packed_f32_valu():
-    """postproc.hip / preproc.hip must compile without v_pk_*_f32: with them the
+    """postproc.hip / preproc.hip / render.hip and the conv kernels must compile without v_pk_*_f32: with them the
     production NMS kernel was not repeatable under MFMA co-residency on gfx950."""
     import shutil
     import subprocess
@@ -315,4 +315,4 @@ def test_bit_exact_kernels_contain_no_packed_f32_valu():
     out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "caffe_rtpose_amd", "csrc"), "check-nopk"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     counts = [int(x) for x in out.stdout.split()]
-    assert counts == [0, 0], out.stdout
+    assert counts == [0, 0, 0, 0, 0], out.stdout   # postproc, preproc, render, conv_ring, conv_igemm
