@@ -768,17 +768,16 @@ void build_enc_huff(EncHuff* h, const unsigned char bits[17], const unsigned cha
 }
 
 struct BitWriter {
-  std::vector<unsigned char>* out;
-  uint32_t acc = 0;
+  unsigned char* p = nullptr;  // the caller guarantees room (worst case 2 bytes per 8 bits written)
+  uint64_t acc = 0;
   int n = 0;
-  void put(unsigned code, int size) {
-    if (!size) return;
-    acc = (acc << size) | (code & ((1u << size) - 1));
+  inline void put(unsigned code, int size) {
+    acc = (acc << size) | (uint64_t)(code & ((1u << size) - 1));
     n += size;
     while (n >= 8) {
-      const unsigned char b = (unsigned char)((acc >> (n - 8)) & 0xFF);
-      out->push_back(b);
-      if (b == 0xFF) out->push_back(0);
+      const unsigned char b = (unsigned char)(acc >> (n - 8));
+      *p++ = b;
+      if (b == 0xFF) *p++ = 0;
       n -= 8;
     }
   }
@@ -788,10 +787,12 @@ struct BitWriter {
 // jfdctint.c jpeg_fdct_islow, in place on level-shifted samples; output scaled by 8
 void fdct_islow(int* data) {
   const int CONST_BITS = 13, PASS1_BITS = 2;
+  typedef int32_t long_t;  // libjpeg's JLONG: every intermediate fits 32 bits for 8-bit samples
+#define long long_t
   const long F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
              F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
              F_2_562915447 = 20995, F_3_072711026 = 25172;
-  auto descale = [](long x, int n) { return (int)((x + (1L << (n - 1))) >> n); };
+  auto descale = [](long x, int n) { return (int)((x + ((long)1 << (n - 1))) >> n); };
   for (int pass = 0; pass < 2; ++pass) {
     const int step = pass ? 8 : 1, next = pass ? 1 : 8;
     for (int i = 0; i < 8; ++i) {
@@ -801,8 +802,8 @@ void fdct_islow(int* data) {
       const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
       long z1 = (tmp12 + tmp13) * F_0_541196100;
       if (!pass) {
-        d[0] = (int)((tmp10 + tmp11) * (1L << PASS1_BITS));
-        d[4 * step] = (int)((tmp10 - tmp11) * (1L << PASS1_BITS));
+        d[0] = (int)((tmp10 + tmp11) * (1 << PASS1_BITS));
+        d[4 * step] = (int)((tmp10 - tmp11) * (1 << PASS1_BITS));
         d[2 * step] = descale(z1 + tmp13 * F_0_765366865, CONST_BITS - PASS1_BITS);
         d[6 * step] = descale(z1 + tmp12 * (-F_1_847759065), CONST_BITS - PASS1_BITS);
       } else {
@@ -824,9 +825,10 @@ void fdct_islow(int* data) {
       d[step] = descale(t7 + z1 + z4, sh);
     }
   }
+#undef long
 }
 
-inline int bit_category(int v) { int a = v < 0 ? -v : v, n = 0; while (a) { ++n; a >>= 1; } return n; }
+inline int bit_category(int v) { const unsigned a = (unsigned)(v < 0 ? -v : v); return a ? 32 - __builtin_clz(a) : 0; }
 
 }  // namespace
 
@@ -854,20 +856,30 @@ extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int qual
     const int H2 = (H + 1) & ~1;                 // rows after padding to max_v_samp_factor (replicate the last row)
     const int fullw = std::max(yw_blocks * 8, cw_blocks * 16);  // expand_right_edge targets
     std::vector<unsigned char> fy((size_t)fullw * H2), fcb((size_t)fullw * H2), fcr((size_t)fullw * H2);
-    for (int y = 0; y < H2; ++y) {
-      const unsigned char* src = bgr + (size_t)std::min(y, H - 1) * W * 3;
-      for (int x = 0; x < fullw; ++x) {
-        const unsigned char* px = src + (size_t)std::min(x, W - 1) * 3;
-        const long r = px[2], g = px[1], b = px[0];
-        fy[(size_t)y * fullw + x] = (unsigned char)((19595L * r + 38470L * g + 7471L * b + 32768L) >> 16);
-        fcb[(size_t)y * fullw + x] = (unsigned char)((-11059L * r - 21709L * g + 32768L * b + (128L << 16) + 32767L) >> 16);
-        fcr[(size_t)y * fullw + x] = (unsigned char)((32768L * r - 27439L * g - 5329L * b + (128L << 16) + 32767L) >> 16);
+    for (int y = 0; y < H; ++y) {
+      const unsigned char* px = bgr + (size_t)y * W * 3;
+      unsigned char* py = &fy[(size_t)y * fullw];
+      unsigned char* pcb = &fcb[(size_t)y * fullw];
+      unsigned char* pcr = &fcr[(size_t)y * fullw];
+      for (int x = 0; x < W; ++x, px += 3) {
+        const int r = px[2], g = px[1], b = px[0];
+        py[x] = (unsigned char)((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+        pcb[x] = (unsigned char)((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16);
+        pcr[x] = (unsigned char)((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16);
       }
+      for (int x = W; x < fullw; ++x) { py[x] = py[W - 1]; pcb[x] = pcb[W - 1]; pcr[x] = pcr[W - 1]; }  // expand_right_edge
+    }
+    if (H2 > H) {  // expand_bottom_edge to max_v_samp_factor rows
+      memcpy(&fy[(size_t)H * fullw], &fy[(size_t)(H - 1) * fullw], fullw);
+      memcpy(&fcb[(size_t)H * fullw], &fcb[(size_t)(H - 1) * fullw], fullw);
+      memcpy(&fcr[(size_t)H * fullw], &fcr[(size_t)(H - 1) * fullw], fullw);
     }
     // luma: copy; rows below the image replicate the last (padded) row up to the iMCU height
     for (int y = 0; y < YH; ++y) {
       const int sy = std::min(y, H2 - 1);
-      for (int x = 0; x < YW; ++x) Y[(size_t)y * YW + x] = fy[(size_t)sy * fullw + std::min(x, yw_blocks * 8 - 1)];
+      const int real = std::min(YW, yw_blocks * 8);
+      memcpy(&Y[(size_t)y * YW], &fy[(size_t)sy * fullw], real);
+      for (int x = real; x < YW; ++x) Y[(size_t)y * YW + x] = fy[(size_t)sy * fullw + real - 1];
     }
     // chroma: h2v2_downsample with bias 1,2,1,2 along the row
     const int crow = H2 / 2, ccol = cw_blocks * 8;
@@ -910,8 +922,13 @@ extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int qual
   EncHuff hdc[2], hac[2];
   build_enc_huff(&hdc[0], kDcLumBits, kDcVals); build_enc_huff(&hac[0], kAcLumBits, kAcLumVals);
   build_enc_huff(&hdc[1], kDcChrBits, kDcVals); build_enc_huff(&hac[1], kAcChrBits, kAcChrVals);
+  const size_t header_bytes = o.size();
+  o.resize(header_bytes + (size_t)mcux * mcuy * 6 * 64 * 4 + 64);  // generous bound for the entropy-coded data
+  uint64_t recip[2][64];
+  for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < 64; ++i) { const uint64_t dv = (uint64_t)qt[t][i] << 3; recip[t][i] = ((1ull << 32) + dv - 1) / dv; }
   BitWriter bw;
-  bw.out = &o;
+  bw.p = o.data() + header_bytes;
   int pred[3] = {0, 0, 0};
   int blk[64], prev_q0 = 0;
   auto code_block = [&](const unsigned char* plane, int stride, int bx, int by, bool real, int comp, int tq) {
@@ -920,12 +937,12 @@ extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int qual
       for (int r = 0; r < 8; ++r)
         for (int c = 0; c < 8; ++c) blk[r * 8 + c] = (int)plane[(size_t)(by * 8 + r) * stride + bx * 8 + c] - 128;
       fdct_islow(blk);
-      for (int i = 0; i < 64; ++i) {
+      for (int i = 0; i < 64; ++i) {  // jcdctmgr.c: round-half-away division by 8*Q (exact reciprocal: |t| < 2^17, 8*Q < 2^11)
         const int qval = qt[tq][i] << 3;
-        int t = blk[i];
-        if (t < 0) { t = -t; t += qval >> 1; t = t >= qval ? t / qval : 0; t = -t; }
-        else { t += qval >> 1; t = t >= qval ? t / qval : 0; }
-        q[i] = t;
+        const int t = blk[i];
+        const unsigned a = (unsigned)(t < 0 ? -t : t) + (unsigned)(qval >> 1);
+        const int m = (int)(((uint64_t)a * recip[tq][i]) >> 32);
+        q[i] = t < 0 ? -m : m;
       }
     } else {  // dummy edge block: zero AC, DC of the previous block (jccoefct.c)
       memset(q, 0, sizeof q);
@@ -945,8 +962,8 @@ extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int qual
       while (run > 15) { bw.put(hac[hidx].code[0xF0], hac[hidx].size[0xF0]); run -= 16; }
       s = bit_category(v);
       const int sym = (run << 4) | s;
-      bw.put(hac[hidx].code[sym], hac[hidx].size[sym]);
-      bw.put((unsigned)(v < 0 ? v - 1 : v), s);
+      // code and value bits in one go (<= 16 + 10 bits)
+      bw.put(((unsigned)hac[hidx].code[sym] << s) | ((unsigned)(v < 0 ? v - 1 : v) & ((1u << s) - 1)), hac[hidx].size[sym] + s);
       run = 0;
     }
     if (run) bw.put(hac[hidx].code[0], hac[hidx].size[0]);
@@ -962,6 +979,7 @@ extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int qual
       code_block(Cr.data(), CW, mx, my, mx < cw_blocks && my < ch_blocks, 2, 1);
     }
   bw.flush();
+  o.resize((size_t)(bw.p - o.data()));
   o.push_back(0xFF); o.push_back(0xD9);
   if (out) {
     if (capacity < o.size()) return cfail(RTP_EINVAL, "output buffer too small");

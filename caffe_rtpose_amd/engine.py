@@ -198,14 +198,11 @@ def decode_image(data):
 def encode_jpeg(bgr, quality=98):
     """cv::imwrite(.jpg) of a BGR HWC u8 image -> bytes."""
     img = np.ascontiguousarray(bgr, np.uint8)
-    n = lib.rtp_encode_jpeg(_u8(img), img.shape[1], img.shape[0], quality, None, 0)
-    if n < 0:
-        raise RtpError(n, lib.rtp_codec_last_error().decode())
-    out = np.empty(n, np.uint8)
+    out = np.empty(img.size * 2 + 4096, np.uint8)   # generous: one pass instead of a size query + encode
     n = lib.rtp_encode_jpeg(_u8(img), img.shape[1], img.shape[0], quality, _u8(out), out.size)
     if n < 0:
         raise RtpError(n, lib.rtp_codec_last_error().decode())
-    return out.tobytes()
+    return out[:n].tobytes()
 
 
 class Video:
