@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -32,6 +33,7 @@
 
 namespace {
 
+const long long kMaxPixels = 1LL << 26;  // 64 Mpixel: refuse absurd headers before allocating for them
 thread_local std::string g_codec_err;
 int cfail(int code, const std::string& m) { g_codec_err = m; return code; }
 
@@ -50,7 +52,8 @@ struct Huff {
   unsigned short fast[512];
 };
 
-void build_huff(Huff* h, const unsigned char bits[17], const unsigned char* vals, int nvals) {
+// false: the code lengths over-subscribe the code space (not a Huffman table)
+bool build_huff(Huff* h, const unsigned char bits[17], const unsigned char* vals, int nvals) {
   memcpy(h->vals, vals, nvals);
   int code = 0, k = 0;
   std::vector<int> codes(nvals), sizes(nvals);
@@ -58,6 +61,7 @@ void build_huff(Huff* h, const unsigned char bits[17], const unsigned char* vals
     h->valptr[l] = k;
     h->mincode[l] = code;
     for (int i = 0; i < bits[l]; ++i) { codes[k] = code++; sizes[k] = l; ++k; }
+    if (code > (1 << l)) return false;
     h->maxcode[l] = bits[l] ? code - 1 : -1;
     code <<= 1;
   }
@@ -69,6 +73,7 @@ void build_huff(Huff* h, const unsigned char bits[17], const unsigned char* vals
     for (int j = 0; j < (1 << (9 - sizes[i])); ++j) h->fast[first + j] = (unsigned short)((sizes[i] << 8) | vals[i]);
   }
   h->set = true;
+  return true;
 }
 
 struct BitReader {
@@ -291,7 +296,7 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       int o = 0;
       while (o < sl) {
         const int pq = s[o] >> 4, tq = s[o] & 15;
-        if (tq > 3) return cfail(RTP_EIO, "JPEG: bad DQT");
+        if (tq > 3 || o + 1 + (pq ? 128 : 64) > sl) return cfail(RTP_EIO, "JPEG: bad DQT");
         ++o;
         for (int i = 0; i < 64; ++i) {
           if (pq) { qt[tq][i] = (uint16_t)((s[o] << 8) | s[o + 1]); o += 2; }
@@ -309,15 +314,19 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
         for (int i = 1; i <= 16; ++i) { bits[i] = s[o + i]; cnt += bits[i]; }
         o += 17;
         if (cnt > 256 || o + cnt > sl) return cfail(RTP_EIO, "JPEG: bad DHT");
-        build_huff(tc ? &hac[th] : &hdc[th], bits, s + o, cnt);
+        if (!build_huff(tc ? &hac[th] : &hdc[th], bits, s + o, cnt)) return cfail(RTP_EIO, "JPEG: invalid Huffman table");
         o += cnt;
       }
     } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {  // SOF0/1 sequential, SOF2 progressive
       progressive = m == 0xC2;
+      if (sl < 6) return cfail(RTP_EIO, "JPEG: truncated SOF");
       if (s[0] != 8) return cfail(RTP_EINVAL, "JPEG: only 8-bit samples are supported");
       H = u16(pos + 3); W = u16(pos + 5);
       const int nc = s[5];
       if (W < 1 || H < 1 || (nc != 1 && nc != 3)) return cfail(RTP_EINVAL, "JPEG: only 1- or 3-component images are supported (no CMYK)");
+      if ((long long)W * H > kMaxPixels) return cfail(RTP_EINVAL, "JPEG: image larger than 64 Mpixel");
+      if (sl < 6 + 3 * nc) return cfail(RTP_EIO, "JPEG: truncated SOF");
+      if (have_sof) return cfail(RTP_EIO, "JPEG: second frame header");
       comps.resize(nc);
       for (int i = 0; i < nc; ++i) {
         comps[i].id = s[6 + 3 * i];
@@ -331,12 +340,13 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
     } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       return cfail(RTP_EINVAL, "JPEG: this coding process is not supported (Huffman sequential and progressive only)");
     } else if (m == 0xDD) {
+      if (sl < 2) return cfail(RTP_EIO, "JPEG: truncated DRI");
       restart = u16(pos + 2);
     } else if (m == 0xEE && sl >= 12 && !memcmp(s, "Adobe", 5)) {
       adobe_transform = s[11];
     } else if (m == 0xDA) {  // SOS: one scan into the coefficient buffers
       if (!have_sof) return cfail(RTP_EIO, "JPEG: SOS before SOF");
-      const int ns = s[0];
+      const int ns = sl >= 1 ? s[0] : 0;
       if (ns < 1 || ns > (int)comps.size() || sl < 1 + 2 * ns + 3) return cfail(RTP_EIO, "JPEG: bad SOS");
       JComp* sc[4];
       for (int i = 0; i < ns; ++i) {
@@ -464,8 +474,12 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       };
       auto do_restart = [&]() {
         br.align_reset();
-        while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
-        if (br.p + 1 < br.end) br.p += 2;
+        // the RSTn marker is normally right here; a damaged stream is searched forward at most once per byte
+        while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) {
+          if (br.p[0] == 0xFF && br.p[1] != 0x00 && br.p[1] != 0xFF) { br.hit_marker = true; break; }  // another marker: the scan is over
+          ++br.p;
+        }
+        if (!br.hit_marker && br.p + 1 < br.end) br.p += 2;
         for (int i = 0; i < ns; ++i) sc[i]->pred = 0;
         eobrun = 0;
       };
@@ -619,6 +633,7 @@ int decode_png(const unsigned char* d, size_t n, unsigned char* out, size_t cap,
       W = (int)be32(data); H = (int)be32(data + 4);
       depth = data[8]; ctype = data[9]; interlace = data[12];
       if (W < 1 || H < 1 || data[10] || data[11] || interlace > 1) return cfail(RTP_EIO, "PNG: bad IHDR");
+      if ((long long)W * H > kMaxPixels) return cfail(RTP_EINVAL, "PNG: image larger than 64 Mpixel");
       have_ihdr = true;
     } else if (!memcmp(type, "PLTE", 4)) pal.assign(data, data + len);
     else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
@@ -1009,8 +1024,12 @@ const char* rtp_codec_last_error(void) { return g_codec_err.c_str(); }
 // cv::imread(path, IMREAD_COLOR) for PNG / JPEG byte strings -> BGR HWC.  out_bgr may be NULL to query the size.
 int rtp_decode_image(const unsigned char* bytes, size_t n, unsigned char* out_bgr, size_t capacity, int* w, int* h) {
   if (!bytes || !w || !h) return RTP_EINVAL;
-  if (n >= 8 && bytes[0] == 0x89 && bytes[1] == 'P') return decode_png(bytes, n, out_bgr, capacity, w, h);
-  if (n >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) return decode_jpeg(bytes, n, out_bgr, capacity, w, h);
+  try {
+    if (n >= 8 && bytes[0] == 0x89 && bytes[1] == 'P') return decode_png(bytes, n, out_bgr, capacity, w, h);
+    if (n >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) return decode_jpeg(bytes, n, out_bgr, capacity, w, h);
+  } catch (const std::exception& ex) {  // nothing may unwind through the C boundary
+    return cfail(RTP_ENOMEM, std::string("image decode: ") + ex.what());
+  }
   return cfail(RTP_EIO, "not a PNG or JPEG byte string");
 }
 
@@ -1053,7 +1072,7 @@ int rtp_video_open(const char* path, rtp_video** out, int* w, int* h, int* nfram
       }
       i = j;
     }
-    if (v->w < 1 || v->h < 1) { delete v; return cfail(RTP_EIO, "Y4M: bad header"); }
+    if (v->w < 1 || v->h < 1 || (long long)v->w * v->h > kMaxPixels) { delete v; return cfail(RTP_EIO, "Y4M: bad header"); }
     const size_t cw = v->chroma == 444 ? v->w : (v->chroma == 400 ? 0 : (v->w + 1) / 2);
     const size_t ch = v->chroma == 420 ? (v->h + 1) / 2 : (v->chroma == 400 ? 0 : v->h);
     v->yuv.resize((size_t)v->w * v->h + 2 * cw * ch);

@@ -345,7 +345,7 @@ static bool parse_blob(Rd r, BlobData* b) {
       if (!r.ok || (uint64_t)(r.e - r.p) < n || (n & 3)) return false;
       const size_t old = b->data.size();
       b->data.resize(old + n / 4);
-      memcpy(b->data.data() + old, r.p, n);
+      if (n) memcpy(b->data.data() + old, r.p, n);  // an empty packed field is legal; memcpy(NULL, .., 0) is not
       r.p += n;
     } else if (fn == 5 && wt == 5) {  // unpacked float
       if (r.e - r.p < 4) return false;

@@ -113,3 +113,37 @@ def test_jpeg_encoder_byte_identical_to_libjpeg(ref):
     assert dec.shape == src.shape
     if q >= 90 and src.shape[0] > 8:
         assert np.abs(dec.astype(int) - src.astype(int)).mean() < 20.0   # noisy source + 4:2:0 chroma
+
+
+def test_decoders_survive_mutated_files():
+    """Untrusted input: corrupted / truncated / spliced files must come back as an image or an error —
+    never a crash or a hang (tools/fuzz_codecs.cpp is the ASan/UBSan version of this loop)."""
+    import random
+    import caffe_rtpose_amd as r
+    files = [open(p, "rb").read() for p in sorted(glob.glob(os.path.join(GOLD, "*.jpg")) + glob.glob(os.path.join(GOLD, "*.png")))]
+    rnd = random.Random(1234)
+    decoded = rejected = 0
+    for _ in range(4000):
+        d = bytearray(rnd.choice(files))
+        mode = rnd.random()
+        if mode < 0.5:
+            for _ in range(rnd.randint(1, 8)):
+                d[rnd.randrange(len(d))] = rnd.randrange(256)
+        elif mode < 0.7:
+            d = d[: rnd.randrange(1, len(d))]
+        elif mode < 0.85:
+            i = rnd.randrange(len(d))
+            d[i:i] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 16)))
+        else:
+            i = rnd.randrange(len(d) - 2)
+            d[i] = 0xFF
+            d[i + 1] = rnd.choice([0xC0, 0xC2, 0xC4, 0xDA, 0xDB, 0xDD, 0xD9, 0xD0, 0xC9])
+        try:
+            img = r.decode_image(bytes(d))
+            assert img.ndim == 3 and img.shape[2] == 3
+            decoded += 1
+        except r.RtpError:
+            rejected += 1
+    assert decoded > 500 and rejected > 500
+    with pytest.raises(r.RtpError):   # absurd header: refused before anything is allocated
+        r.decode_image(b"\x89PNG\r\n\x1a\n\x00\x00\x00\rIHDR" + (70000).to_bytes(4, "big") + (70000).to_bytes(4, "big") + b"\x08\x02\x00\x00\x00" + b"\0" * 12)
