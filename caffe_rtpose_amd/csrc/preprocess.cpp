@@ -232,7 +232,7 @@ int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, in
       return v;
     };
     const int W = next_int(), H = next_int(), maxv = next_int();
-    if (W < 1 || H < 1 || maxv != 255) return RTP_EIO;
+    if (W < 1 || H < 1 || maxv != 255 || (long long)W * H > (1LL << 26)) return RTP_EIO;  // same 64 Mpixel cap as codecs.cpp
     *w = W; *h = H;
     if (!out_bgr) return RTP_OK;
     if (capacity < (size_t)W * H * 3) return RTP_EINVAL;
@@ -250,7 +250,7 @@ int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, in
     const int32_t W = (int32_t)u32(16), Hs = (int32_t)u32(20);
     const int bpp = hdr[26] | (hdr[27] << 8);
     const uint32_t comp = u32(28);
-    if (W < 1 || Hs == 0 || bpp != 24 || comp != 0) return RTP_EIO;
+    if (W < 1 || Hs == 0 || Hs == INT32_MIN || bpp != 24 || comp != 0 || (long long)W * (Hs < 0 ? -(long long)Hs : Hs) > (1LL << 26)) return RTP_EIO;
     const int H = Hs < 0 ? -Hs : Hs;
     *w = W; *h = H;
     if (!out_bgr) return RTP_OK;
