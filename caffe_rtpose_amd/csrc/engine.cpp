@@ -953,7 +953,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   delete e;
 }
 
-int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
+static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (!cfg || !out) return fail(nullptr, RTP_EINVAL, "null argument");
   *out = nullptr;
   if (cfg->num_scales < 1 || cfg->num_scales > 16) return fail(nullptr, RTP_EINVAL, "num_scales %d out of range", cfg->num_scales);
@@ -1544,7 +1544,7 @@ int rtp_caffemodel_layer(const char* path, int index, char* name, int name_len, 
 
 // Build the execution plan for cfg WITHOUT touching a device and describe it as text (tensors,
 // per-layer tile configuration, branch pairing, arena sizes).  Host logic only.
-long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
+static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   if (!cfg || !buf) return RTP_EINVAL;
   rtp_engine* e = new rtp_engine();
   e->cfg = *cfg;
@@ -1702,6 +1702,24 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   (void)nprob;
   if (flops_per_launch) *flops_per_launch = fl;
   return RTP_OK;
+}
+
+// Nothing may unwind through the C boundary: allocation failures while building a plan come back as codes.
+int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
+  try {
+    return engine_create_impl(cfg, out);
+  } catch (const std::bad_alloc&) {
+    return fail(nullptr, RTP_ENOMEM, "out of host memory while creating the engine");
+  } catch (const std::exception& ex) {
+    return fail(nullptr, RTP_EINVAL, "engine creation failed: %s", ex.what());
+  }
+}
+long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
+  try {
+    return plan_summary_impl(cfg, buf, buflen);
+  } catch (const std::exception& ex) {
+    return fail(nullptr, RTP_ENOMEM, "plan summary failed: %s", ex.what());
+  }
 }
 
 }  // extern "C"
