@@ -8,6 +8,7 @@
 // all forced by the environment: no display/camera (no GUI stack), image decoding limited to
 // JPEG/PNG/PPM/BMP and Y4M / raw MJPEG (codecs.cpp), `--video synthetic:WxH:frames[:seed]` generates frames procedurally, and the
 // process exits at end of input also without --write_frames (the reference loops the video forever).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>

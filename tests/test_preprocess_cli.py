@@ -229,3 +229,16 @@ def test_cli_write_frames_jpeg_equals_library_render(tmp_path):
     e.close()
     p = subprocess.run([BIN, "--video", "synthetic:64x48:1", "--model", "coco", "--write_frames", str(tmp_path / "x"), "--host_preprocess"], capture_output=True)
     assert p.returncode == 1 and b"--write_frames needs" in p.stderr
+
+
+def test_cli_reorderer_order_drops_and_window(tmp_path):
+    """Row a12 without a GPU: the CLI's re-orderer (buffer_and_order, rtpose.cpp:1214-1273) on hand-fed frames."""
+    exe = tmp_path / "reorder_check"
+    src = os.path.join(ROOT, "tests", "helpers", "reorder_check.cpp")
+    libdir = os.path.join(ROOT, "caffe_rtpose_amd")
+    p = subprocess.run(["g++", "-O1", "-std=c++17", src, "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lrtpose_mi355x",
+                        "-Wl,-rpath," + libdir, "-lpthread", "-o", str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok ") == 5
