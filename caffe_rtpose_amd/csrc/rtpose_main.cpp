@@ -178,6 +178,7 @@ void producer() {
   // the producer still hands the frames over in file order, like the reference's single loop
   struct Decoded { std::vector<unsigned char> bgr; int w = 0, h = 0; std::string err; };
   std::deque<std::future<Decoded>> ahead;
+  const int decode_ahead = std::max(2, std::min(16, (int)std::thread::hardware_concurrency() / 4));  // 13 ms per 720p JPEG and core
   int next_to_decode = F.start_frame;
   auto decode_file = [](std::string path) {
     Decoded d;
@@ -203,7 +204,7 @@ void producer() {
       char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm;
     } else {
       const std::string& path = G.image_list[fi];
-      while (next_to_decode < nframes && (int)ahead.size() < 8) ahead.push_back(std::async(std::launch::async, decode_file, G.image_list[next_to_decode++]));
+      while (next_to_decode < nframes && (int)ahead.size() < decode_ahead) ahead.push_back(std::async(std::launch::async, decode_file, G.image_list[next_to_decode++]));
       Decoded d = ahead.front().get();
       ahead.pop_front();
       if (d.w == 0) { fprintf(stderr, "cannot decode %s: %s\n", path.c_str(), d.err.c_str()); continue; }
