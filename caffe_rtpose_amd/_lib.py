@@ -32,6 +32,7 @@ class rtp_config(C.Structure):
         ("frames_in_flight", C.c_int),
         ("batch_frames", C.c_int),
         ("render", C.c_int),
+        ("exec_mode", C.c_int),
     ]
 
 

@@ -555,19 +555,22 @@ int decode_jpeg(const unsigned char* d, size_t n, unsigned char* out, size_t cap
         return RTP_OK;
       }
       // jdcolor.c build_ycc_rgb_table / ycc_rgb_convert
-      static int cr_r[256], cb_b[256];
-      static long cr_g[256], cb_g[256];
-      static bool tabs = false;
-      if (!tabs) {
-        for (int i = 0; i < 256; ++i) {
-          const long x = i - 128;
-          cr_r[i] = (int)((91881L * x + 32768L) >> 16);
-          cb_b[i] = (int)((116130L * x + 32768L) >> 16);
-          cr_g[i] = -46802L * x;
-          cb_g[i] = -22554L * x + 32768L;
+      struct YccTab {  // built once, thread-safely (C++11 static initialisation): decoders run on several threads
+        int cr_r[256], cb_b[256];
+        long cr_g[256], cb_g[256];
+        YccTab() {
+          for (int i = 0; i < 256; ++i) {
+            const long x = i - 128;
+            cr_r[i] = (int)((91881L * x + 32768L) >> 16);
+            cb_b[i] = (int)((116130L * x + 32768L) >> 16);
+            cr_g[i] = -46802L * x;
+            cb_g[i] = -22554L * x + 32768L;
+          }
         }
-        tabs = true;
-      }
+      };
+      static const YccTab T;
+      const int* cr_r = T.cr_r; const int* cb_b = T.cb_b;
+      const long* cr_g = T.cr_g; const long* cb_g = T.cb_g;
       for (size_t i = 0; i < (size_t)W * H; ++i) {
         const int y = f[0][i], cb = f[1][i], cr = f[2][i];
         out[i * 3 + 2] = clamp255(y + cr_r[cr]);
@@ -847,7 +850,15 @@ inline int bit_category(int v) { const unsigned a = (unsigned)(v < 0 ? -v : v); 
 
 }  // namespace
 
+static long encode_jpeg_impl(const unsigned char* bgr, int W, int H, int quality, unsigned char* out, size_t capacity);
 extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int quality, unsigned char* out, size_t capacity) {
+  try {
+    return encode_jpeg_impl(bgr, W, H, quality, out, capacity);
+  } catch (const std::exception& ex) {  // nothing may unwind through the C boundary
+    return cfail(RTP_ENOMEM, std::string("JPEG encode: ") + ex.what());
+  }
+}
+static long encode_jpeg_impl(const unsigned char* bgr, int W, int H, int quality, unsigned char* out, size_t capacity) {
   if (!bgr || W < 1 || H < 1 || W > 65535 || H > 65535) return RTP_EINVAL;
   if (quality < 1) quality = 1;
   if (quality > 100) quality = 100;
@@ -938,7 +949,8 @@ extern "C" long rtp_encode_jpeg(const unsigned char* bgr, int W, int H, int qual
   build_enc_huff(&hdc[0], kDcLumBits, kDcVals); build_enc_huff(&hac[0], kAcLumBits, kAcLumVals);
   build_enc_huff(&hdc[1], kDcChrBits, kDcVals); build_enc_huff(&hac[1], kAcChrBits, kAcChrVals);
   const size_t header_bytes = o.size();
-  o.resize(header_bytes + (size_t)mcux * mcuy * 6 * 64 * 4 + 64);  // generous bound for the entropy-coded data
+  // worst case per coefficient: 16-bit Huffman code + 11 value bits, every output byte 0xFF and stuffed => < 8 bytes
+  o.resize(header_bytes + (size_t)mcux * mcuy * 6 * 64 * 8 + 64);
   uint64_t recip[2][64];
   for (int t = 0; t < 2; ++t)
     for (int i = 0; i < 64; ++i) { const uint64_t dv = (uint64_t)qt[t][i] << 3; recip[t][i] = ((1ull << 32) + dv - 1) / dv; }
@@ -1020,6 +1032,7 @@ struct rtp_video {
 extern "C" {
 
 const char* rtp_codec_last_error(void) { return g_codec_err.c_str(); }
+int rtp_internal_codec_fail(int code, const char* msg) { return cfail(code, msg ? msg : ""); }  // for the PPM/BMP loader in preprocess.cpp
 
 // cv::imread(path, IMREAD_COLOR) for PNG / JPEG byte strings -> BGR HWC.  out_bgr may be NULL to query the size.
 int rtp_decode_image(const unsigned char* bytes, size_t n, unsigned char* out_bgr, size_t capacity, int* w, int* h) {
@@ -1040,7 +1053,23 @@ int rtp_internal_load_png_jpeg(const char* path, unsigned char* out_bgr, size_t 
 }
 
 // cv::VideoCapture(path) for the two container-less formats decodable here.
+static int video_open_impl(const char* path, rtp_video** out, int* w, int* h, int* nframes);
+static int video_read_impl(rtp_video* v, unsigned char* out_bgr, size_t capacity);
 int rtp_video_open(const char* path, rtp_video** out, int* w, int* h, int* nframes) {
+  try {
+    return video_open_impl(path, out, w, h, nframes);
+  } catch (const std::exception& ex) {
+    return cfail(RTP_ENOMEM, std::string("video open: ") + ex.what());
+  }
+}
+int rtp_video_read(rtp_video* v, unsigned char* out_bgr, size_t capacity) {
+  try {
+    return video_read_impl(v, out_bgr, capacity);
+  } catch (const std::exception& ex) {
+    return cfail(RTP_ENOMEM, std::string("video read: ") + ex.what());
+  }
+}
+static int video_open_impl(const char* path, rtp_video** out, int* w, int* h, int* nframes) {
   if (!path || !out) return RTP_EINVAL;
   rtp_video* v = new rtp_video();
   v->f.open(path, std::ios::binary);
@@ -1104,7 +1133,7 @@ int rtp_video_open(const char* path, rtp_video** out, int* w, int* h, int* nfram
 }
 
 // next frame -> BGR HWC; RTP_EAGAIN at the end of the stream
-int rtp_video_read(rtp_video* v, unsigned char* out_bgr, size_t capacity) {
+static int video_read_impl(rtp_video* v, unsigned char* out_bgr, size_t capacity) {
   if (!v || !out_bgr) return RTP_EINVAL;
   if (capacity < (size_t)v->w * v->h * 3) return cfail(RTP_EINVAL, "output buffer too small");
   if (v->kind == 1) {

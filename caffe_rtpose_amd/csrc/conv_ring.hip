@@ -185,7 +185,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   const BlockCoord bc = decode_block(P, P.CoutP / BN, P.tiles_per_img * P.nimg);
   const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;
-  if (P.tstamp && tid == 0) atomicMin(&P.tstamp[0], (unsigned long long)wall_clock64());
+  if (P.tstamp && tid == 0) atomicMax(&P.tstamp[0], ~(unsigned long long)wall_clock64());  // slot = {~(min start), max end}, both zero-initialised
   const int lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = SPEC && wave_all >= 4;

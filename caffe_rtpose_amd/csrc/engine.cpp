@@ -113,7 +113,17 @@ struct Ctx {
   std::vector<Slot> slot;
   int filled = 0;        // frames staged in the open batch
   bool launched = false;
+  // RTP_EXEC_GRAPH: the whole batch (conv stack, every frame's post-processing chain, D2H) captured once
+  // per (timed?, frames in the batch) and replayed; gev = {before, after} the replay on `stream`
+  hipGraphExec_t gexec[2][17] = {};
+  hipEvent_t gev[2] = {nullptr, nullptr};
+  bool graph_run = false;                 // the batch in flight was a graph replay (collect waits on gev[1])
+  unsigned long long* ts_dev = nullptr;   // in-kernel {~start, end} stamps of the dominant-class launches of one replay
+  unsigned long long* ts_host = nullptr;  // pinned copy, written by the graph after the conv stack
+  int ts_n = 0;
+  bool ts_pending = false;
 };
+const int CTX_TS_SLOTS = 64;
 
 }  // namespace
 
@@ -158,7 +168,8 @@ struct rtp_engine {
   std::vector<AreaScale> area_scales;   // device pointers inside prep_tables
   unsigned char* prep_tables = nullptr;
   bool gpu_prep_ok = false;
-  unsigned long long* ts_ring = nullptr;  // device: {min start, max end} per timed launch
+  bool use_graph = true;
+  unsigned long long* ts_ring = nullptr;  // device: {~(min start), max end} per timed launch (eager mode)
   int ts_next = 0;
   static const int TS_SLOTS = 32768;
 };
@@ -618,18 +629,22 @@ bool is_dominant_class(const rtp_engine* e, const Step& s) {
   return a.k == d.k && a.cin == d.cin && a.cout == d.cout && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
 }
 
-int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg) {
+int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bool cap = false) {
   const std::vector<PoolOp>& pools = e->pools;
   auto geom_n = [&](int level) { Geom g = e->geom[level]; g.N = nimg; return g; };
+  if (cap) cx.ts_n = 0;
   for (auto& s : e->steps) {
     if (s.type == 0) {
       const Tensor& t = e->tensors[0];
       HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, geom_n(0), t.Cp, cx.stream));
     } else if (s.type == 1) {
-      const bool timed = e->time_dominant && e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS && is_dominant_class(e, s);
-      const int rc = launch_conv_step(e, cx, s, nimg, timed ? e->ts_ring + 2 * (size_t)e->ts_next : nullptr);
+      unsigned long long* ts = nullptr;
+      if (e->time_dominant && is_dominant_class(e, s)) {
+        if (cap) { if (cx.ts_dev && cx.ts_n < CTX_TS_SLOTS) ts = cx.ts_dev + 2 * (size_t)cx.ts_n++; }
+        else if (e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS) ts = e->ts_ring + 2 * (size_t)e->ts_next++;
+      }
+      const int rc = launch_conv_step(e, cx, s, nimg, ts);
       if (rc) return rc;
-      if (timed) e->ts_next++;
     } else {
       const PoolOp& p = pools[s.a];
       const Tensor& ti = e->tensors[p.in_tensor];
@@ -696,10 +711,14 @@ int run_post_fused(rtp_engine* e, Ctx& cx, int sj, hipEvent_t ev_nms) {
 
 // one batch on one context: conv stack over nframes*num_scales images, then per frame (on the
 // frame slot's stream) resize -> nms -> connect -> D2H of the joints
-int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize = false) {
+int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize, bool cap) {
   int rc;
   HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
-  if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N))) return rc;
+  if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N, cap))) return rc;
+  if (cap && cx.ts_n > 0) {  // hand the stamps of this replay to the host and re-arm the slots
+    HIPCHK(e, hipMemcpyAsync(cx.ts_host, cx.ts_dev, (size_t)2 * cx.ts_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, cx.stream));
+    HIPCHK(e, hipMemsetAsync(cx.ts_dev, 0, (size_t)2 * cx.ts_n * sizeof(unsigned long long), cx.stream));
+  }
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
   const size_t jbytes = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3 * sizeof(float);
   for (int j = 0; j < nframes; ++j) {
@@ -737,7 +756,49 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
     HIPCHK(e, hipMemcpyAsync(sl.host_out + 4, sl.joints, jbytes, hipMemcpyDeviceToHost, sl.stream));
     HIPCHK(e, hipMemcpyAsync(sl.host_out, sl.num_people, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
     HIPCHK(e, hipEventRecord(sl.ev[4], sl.stream));
+    if (cap && sl.stream != cx.stream) HIPCHK(e, hipStreamWaitEvent(cx.stream, sl.ev[4], 0));  // join the capture
   }
+  return RTP_OK;
+}
+
+// Static launch plan as a hipGraph: captured the first time a batch of `nframes` frames is launched on
+// this context (stream capture of exactly the eager sequence; the frame slots' streams fork from and
+// join the context's stream), then ONE hipGraphLaunch per batch.  Replaces net.cpp:544-556.
+int capture_batch(rtp_engine* e, Ctx& cx, int nframes, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  HIPCHK(e, hipStreamBeginCapture(cx.stream, hipStreamCaptureModeThreadLocal));
+  const int rc = launch_batch_body(e, cx, nframes, cx.input, false, true);
+  const hipError_t s = hipStreamEndCapture(cx.stream, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (s != hipSuccess || !g) return fail(e, RTP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(s));
+  const hipError_t si = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (si != hipSuccess) return fail(e, RTP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(si));
+  return RTP_OK;
+}
+
+int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize = false) {
+  int rc;
+  static const char* diag = getenv("RTP_DIAG_SKIP_POST");
+  static const char* unf = getenv("RTP_POST_UNFUSED");
+  const bool graph = e->use_graph && !materialize && input_dev == cx.input && !e->cfg.render && !diag && !unf && nframes <= 16;
+  cx.graph_run = graph;
+  if (!graph) {
+    if ((rc = launch_batch_body(e, cx, nframes, input_dev, materialize, false))) return rc;
+    cx.launched = true;
+    return RTP_OK;
+  }
+  const int t = e->time_dominant ? 1 : 0;
+  if (t && !cx.ts_dev) {
+    HIPCHK(e, hipMalloc((void**)&cx.ts_dev, (size_t)2 * CTX_TS_SLOTS * sizeof(unsigned long long)));
+    HIPCHK(e, hipMemset(cx.ts_dev, 0, (size_t)2 * CTX_TS_SLOTS * sizeof(unsigned long long)));
+    HIPCHK(e, hipHostMalloc((void**)&cx.ts_host, (size_t)2 * CTX_TS_SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  if (!cx.gexec[t][nframes] && (rc = capture_batch(e, cx, nframes, &cx.gexec[t][nframes]))) return rc;
+  HIPCHK(e, hipEventRecord(cx.gev[0], cx.stream));
+  HIPCHK(e, hipGraphLaunch(cx.gexec[t][nframes], cx.stream));
+  HIPCHK(e, hipEventRecord(cx.gev[1], cx.stream));
+  cx.ts_pending = t != 0;
   cx.launched = true;
   return RTP_OK;
 }
@@ -781,6 +842,7 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   HIPCHK(e, hipMalloc((void**)&cx.lowres, low_floats * sizeof(float)));
   HIPCHK(e, hipMemset(cx.lowres, 0, low_floats * sizeof(float)));
   for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.ev[i]));
+  for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.gev[i]));
   cx.slot.resize(e->B);
   for (int j = 0; j < e->B; ++j) {
     int rc;
@@ -802,10 +864,13 @@ void free_ctx(Ctx& cx) {
     for (int i = 0; i < 5; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
   }
-  void* dptrs[] = {cx.arena, cx.input, cx.lowres};
+  for (auto& row : cx.gexec) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+  void* dptrs[] = {cx.arena, cx.input, cx.lowres, cx.ts_dev};
   for (void* p : dptrs) if (p) (void)hipFree(p);
   if (cx.host_in) (void)hipHostFree(cx.host_in);
+  if (cx.ts_host) (void)hipHostFree(cx.ts_host);
   for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
+  for (int i = 0; i < 2; ++i) if (cx.gev[i]) (void)hipEventDestroy(cx.gev[i]);
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
   cx = Ctx();
 }
@@ -935,6 +1000,7 @@ int rtp_config_default(rtp_config* cfg) {
   cfg->precision = RTP_PREC_FP16;
   cfg->frames_in_flight = 2;
   cfg->batch_frames = 1;
+  cfg->exec_mode = RTP_EXEC_GRAPH;
   return RTP_OK;
 }
 
@@ -960,6 +1026,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 64) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
   if (cfg->batch_frames < 0 || cfg->batch_frames > 16) return fail(nullptr, RTP_EINVAL, "batch_frames %d out of range", cfg->batch_frames);
   if (cfg->precision != RTP_PREC_FP16 && cfg->precision != RTP_PREC_FP32) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
+  if (cfg->exec_mode != RTP_EXEC_GRAPH && cfg->exec_mode != RTP_EXEC_EAGER) return fail(nullptr, RTP_EINVAL, "unknown exec_mode %d", cfg->exec_mode);
   if (cfg->disp_w < 1 || cfg->disp_h < 1) return fail(nullptr, RTP_EINVAL, "bad display resolution");
   // CHECK_LE(target_width, NET_RESOLUTION_WIDTH) (rtpose.cpp:363): every scale must fit the net input
   for (int i = 0; i < cfg->num_scales; ++i) {
@@ -985,6 +1052,12 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   e->NI = e->N * e->B;
   e->start_scale = cfg->start_scale;
   e->scale_gap = cfg->scale_gap;
+  {
+    const char* eg = getenv("RTP_EXEC");  // experiments: override the execution mode ("eager" / "graph")
+    e->use_graph = cfg->exec_mode == RTP_EXEC_GRAPH;
+    if (eg && !strcmp(eg, "eager")) e->use_graph = false;
+    if (eg && !strcmp(eg, "graph")) e->use_graph = true;
+  }
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
 
   if (!e->proto_path.empty()) {
@@ -1049,11 +1122,17 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
     hipError_t s = hipMemsetAsync(cx.input, 0, in_floats * sizeof(float), cx.stream);
     if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "hipMemsetAsync failed"));
-    if ((rc = enqueue_frame(e, cx, cx.input))) return bail(rc);
-    cx.launched = false;
+    if ((rc = launch_batch_body(e, cx, 1, cx.input, false, false))) return bail(rc);  // eager: also sets the kernels' LDS attributes
     s = hipStreamSynchronize(cx.stream);
     if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s)));
+    for (Slot& sl : cx.slot) {
+      s = hipStreamSynchronize(sl.stream);
+      if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s)));
+    }
   }
+  if (e->use_graph && !e->cfg.render)  // capture the full-batch plan of every context now, not inside the first frames
+    for (auto& c : e->ctx)
+      if ((rc = capture_batch(e, c, e->B, &c.gexec[0][e->B]))) return bail(rc);
   *out = e;
   return RTP_OK;
 }
@@ -1107,7 +1186,7 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
-  if (e->B == 1) {  // no staging copy: the conv stack reads the caller's tensor
+  if (e->B == 1 && !e->use_graph) {  // eager: no staging copy, the conv stack reads the caller's tensor
     cx.slot[0].tag = tag;
     cx.slot[0].busy = true;
     cx.slot[0].has_disp = false;
@@ -1182,6 +1261,13 @@ int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, 
 int rtp_in_flight(const rtp_engine* e) { return e ? (int)e->fifo.size() : 0; }
 
 static void stage_ms(rtp_engine* e, Ctx& cx, Slot& sl) {
+  if (cx.graph_run) {  // events recorded inside a capture carry no time: only the whole replay is bracketed
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, cx.gev[0], cx.gev[1]);
+    for (int i = 0; i < 4; ++i) e->last_ms[i] = 0.f;
+    e->last_ms[4] = ms;
+    return;
+  }
   hipEvent_t a[5] = {cx.ev[0], sl.ev[0], sl.ev[1], sl.ev[2], cx.ev[0]};
   hipEvent_t b[5] = {cx.ev[1], sl.ev[1], sl.ev[2], sl.ev[3], sl.ev[4]};
   for (int i = 0; i < 5; ++i) {
@@ -1208,7 +1294,16 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   Ctx& cx = e->ctx[ci];
   Slot& sl = cx.slot[sj];
   if (!cx.launched && (rc = launch_open(e))) return rc;  // the oldest frame sits in a partial batch
-  HIPCHK(e, hipEventSynchronize(sl.ev[4]));
+  HIPCHK(e, hipEventSynchronize(cx.graph_run ? cx.gev[1] : sl.ev[4]));
+  if (cx.graph_run && cx.ts_pending) {  // dominant-kernel stamps of this replay (rtp_kernel_timing)
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
+    for (int i = 0; i < cx.ts_n; ++i) {
+      const unsigned long long st = ~cx.ts_host[2 * i], en = cx.ts_host[2 * i + 1];
+      if (cx.ts_host[2 * i] != 0 && en > st) { e->dom_ms_total += (double)(en - st) / (double)khz; e->dom_launches++; }
+    }
+    cx.ts_pending = false;
+  }
   e->fifo.pop_front();
   sl.busy = false;
   bool any = false;
@@ -1304,8 +1399,16 @@ int rtp_post_from_lowres(rtp_engine* e, const float* lowres, float* peaks, float
   const size_t pbytes = (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float);
   HIPCHK(e, hipMemcpy(cx.lowres, lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyHostToDevice));
   if (peaks) HIPCHK(e, hipMemcpy(sl.peaks, peaks, pbytes, hipMemcpyHostToDevice));  // stale slots stay, like the reference's blob
+  HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
   if ((rc = run_post_fused(e, cx, 0, sl.ev[2]))) return rc;
+  HIPCHK(e, hipEventRecord(sl.ev[3], sl.stream));
   HIPCHK(e, hipStreamSynchronize(sl.stream));
+  {  // rtp_last_stage_ms: {-, -, nms, connect, both} of this call
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, sl.ev[1], sl.ev[2]);
+    (void)hipEventElapsedTime(&b, sl.ev[2], sl.ev[3]);
+    e->last_ms[0] = e->last_ms[1] = 0.f; e->last_ms[2] = a; e->last_ms[3] = b; e->last_ms[4] = a + b;
+  }
   if (peaks) HIPCHK(e, hipMemcpy(peaks, sl.peaks, pbytes, hipMemcpyDeviceToHost));
   int n = 0;
   HIPCHK(e, hipMemcpy(&n, sl.num_people, sizeof(int), hipMemcpyDeviceToHost));
@@ -1606,8 +1709,10 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     HIPCHK(e, hipMemcpy(h.data(), e->ts_ring, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     int khz = 100000;
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
-    for (int i = 0; i < e->ts_next; ++i)
-      if (h[2 * i + 1] > h[2 * i]) { e->dom_ms_total += (double)(h[2 * i + 1] - h[2 * i]) / (double)khz; e->dom_launches++; }
+    for (int i = 0; i < e->ts_next; ++i) {
+      const unsigned long long st = ~h[2 * i], en = h[2 * i + 1];
+      if (h[2 * i] != 0 && en > st) { e->dom_ms_total += (double)(en - st) / (double)khz; e->dom_launches++; }
+    }
     e->ts_next = 0;
   }
   if (total_ms) *total_ms = e->dom_ms_total;
@@ -1622,13 +1727,12 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     *flops_per_launch = fl;
   }
   if (enable >= 0) {
-    if ((enable != 0) != e->time_dominant) { e->dom_ms_total = 0; e->dom_launches = 0; }
+    if ((enable != 0) != e->time_dominant && !e->fifo.empty()) return fail(e, RTP_EAGAIN, "kernel timing can only be switched on an idle engine");
+    if ((enable != 0) != e->time_dominant || enable == 2) { e->dom_ms_total = 0; e->dom_launches = 0; }  // 2 = on + reset
     e->time_dominant = enable != 0;
     if (e->time_dominant) {
       if (!e->ts_ring) HIPCHK(e, hipMalloc((void**)&e->ts_ring, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
-      std::vector<unsigned long long> init((size_t)2 * rtp_engine::TS_SLOTS);
-      for (int i = 0; i < rtp_engine::TS_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
-      HIPCHK(e, hipMemcpy(e->ts_ring, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+      HIPCHK(e, hipMemset(e->ts_ring, 0, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
       e->ts_next = 0;
     }
   }

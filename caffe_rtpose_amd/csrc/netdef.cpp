@@ -220,8 +220,9 @@ bool parse_prototxt(const std::string& text, NetDef* out, std::string* err) {
       if (c->get("stride", &v)) L.stride = to_i(v);
       if (c->get("bias_term", &v)) L.bias_term = (v == "true" || v == "1");
       std::string kh, kw, g, dl;
-      if (c->get("kernel_h", &kh) || c->get("kernel_w", &kw)) {
-        if (to_i(kh) != to_i(kw)) { *err = "layer " + L.name + ": non-square kernels are outside the linevec path"; return false; }
+      const bool has_kh = c->get("kernel_h", &kh), has_kw = c->get("kernel_w", &kw);  // Caffe accepts kernel_size or the h/w pair
+      if (has_kh || has_kw) {
+        if (!(has_kh && has_kw) || to_i(kh) != to_i(kw)) { *err = "layer " + L.name + ": non-square kernels are outside the linevec path"; return false; }
         L.kernel = to_i(kh);
       }
       if (c->get("group", &g) && to_i(g) != 1) { *err = "layer " + L.name + ": group != 1 is outside the linevec path"; return false; }
@@ -334,9 +335,11 @@ static bool parse_blob(Rd r, BlobData* b) {
         const uint64_t k2 = s.varint();
         if ((k2 >> 3) == 1 && (k2 & 7) == 2) {
           const uint64_t m = s.varint();
+          if (!s.ok || (uint64_t)(s.e - s.p) < m || m > 64) return false;  // packed dims stay inside the BlobShape; a blob has a handful of axes
           Rd d{s.p, s.p + m};
           s.p += m;
           while (d.p < d.e && d.ok) b->shape.push_back((int64_t)d.varint());
+          if (!d.ok) return false;
         } else if ((k2 >> 3) == 1 && (k2 & 7) == 0) b->shape.push_back((int64_t)s.varint());
         else if (!s.skip((int)(k2 & 7))) return false;
       }

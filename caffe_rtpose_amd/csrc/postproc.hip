@@ -21,6 +21,8 @@
 //            raster order, ballot-compacted; then lane 0 runs the libstdc++-exact sort and the
 //            greedy assignment) and a single-wavefront assembly kernel that keeps the person
 //            table in LDS and parallelises the row searches over the 64 lanes.
+#include <atomic>
+
 #include "kernels.h"
 #include "stdsort_replica.h"
 
@@ -523,11 +525,25 @@ __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, Resiz
   if (tid == 0 && blockIdx.y == 0) dst[0] = (float)total;  // unclamped total, nms_layer.cu:110
 }
 
+// >64 KiB dynamic LDS opt-in, once per (kernel, device, size): hipFuncSetAttribute is a driver call
+// (it was issued per launch) and has no place inside a stream capture.
+template <auto KERN>  // one cache per kernel (not per kernel TYPE: several kernels share a signature)
+static hipError_t ensure_lds(size_t bytes) {
+  static std::atomic<size_t> have[32];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t>& h = have[dev & 31];
+  if (h.load(std::memory_order_relaxed) >= bytes) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) h.store(bytes, std::memory_order_relaxed);
+  return e;
+}
+
 hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream) {
   const size_t lds1 = (size_t)(p.strip_rows + 2 + NMSF_TROWS) * p.W * sizeof(float);
   if (lds1 > 150 * 1024) return hipErrorInvalidValue;
   if (lds1 > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)nms_fused_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipError_t e = ensure_lds<nms_fused_strip_kernel>(lds1);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(nms_fused_strip_kernel, dim3(p.nstrips, p.num_parts), dim3(256), lds1, stream, p, r);
@@ -1051,18 +1067,18 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
     if (pa.assemble_preload) lds2 += extra;
   }
   if (lds1 > 64 * 1024) {
-    e = hipFuncSetAttribute((const void*)connect_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    e = ensure_lds<connect_match_kernel>(lds1);
     if (e != hipSuccess) return e;
   }
   if (lds2 > 64 * 1024) {
-    e = hipFuncSetAttribute((const void*)connect_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    e = ensure_lds<connect_assemble_kernel>(lds2);
     if (e != hipSuccess) return e;
   }
   if (r) {
     const size_t lds0 = (size_t)2 * r->num * r->h * r->w * sizeof(float);
     const int stage = lds0 <= 96 * 1024 ? 1 : 0;
     if (stage && lds0 > 64 * 1024) {
-      e = hipFuncSetAttribute((const void*)connect_pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+      e = ensure_lds<connect_pairs_kernel<true>>(lds0);
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), stage ? lds0 : 0, stream, p, *r, stage);

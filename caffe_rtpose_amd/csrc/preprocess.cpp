@@ -213,10 +213,11 @@ int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int
 }
 
 // ---- image files we can decode without OpenCV: binary PPM (P6) and 24-bit uncompressed BMP ------
+extern "C" int rtp_internal_codec_fail(int code, const char* msg);
 int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, int* w, int* h) {
   if (!path || !w || !h) return RTP_EINVAL;
   std::ifstream f(path, std::ios::binary);
-  if (!f) return RTP_EIO;
+  if (!f) return rtp_internal_codec_fail(RTP_EIO, (std::string("cannot open ") + path).c_str());
   unsigned char magic[2] = {0, 0};
   f.read((char*)magic, 2);
   if (magic[0] == 'P' && magic[1] == '6') {
@@ -232,25 +233,25 @@ int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, in
       return v;
     };
     const int W = next_int(), H = next_int(), maxv = next_int();
-    if (W < 1 || H < 1 || maxv != 255 || (long long)W * H > (1LL << 26)) return RTP_EIO;  // same 64 Mpixel cap as codecs.cpp
+    if (W < 1 || H < 1 || maxv != 255 || (long long)W * H > (1LL << 26)) return rtp_internal_codec_fail(RTP_EIO, "PPM: bad header (need P6, maxval 255, <= 64 Mpixel)");  // same 64 Mpixel cap as codecs.cpp
     *w = W; *h = H;
     if (!out_bgr) return RTP_OK;
     if (capacity < (size_t)W * H * 3) return RTP_EINVAL;
     f.read((char*)out_bgr, (std::streamsize)W * H * 3);
-    if (!f) return RTP_EIO;
+    if (!f) return rtp_internal_codec_fail(RTP_EIO, "PPM: truncated pixel data");
     for (size_t i = 0; i < (size_t)W * H; ++i) std::swap(out_bgr[i * 3], out_bgr[i * 3 + 2]);  // RGB -> BGR
     return RTP_OK;
   }
   if (magic[0] == 'B' && magic[1] == 'M') {
     unsigned char hdr[52];
     f.read((char*)hdr, 52);
-    if (!f) return RTP_EIO;
+    if (!f) return rtp_internal_codec_fail(RTP_EIO, "BMP: truncated header");
     auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
     const uint32_t data_off = u32(8);
     const int32_t W = (int32_t)u32(16), Hs = (int32_t)u32(20);
     const int bpp = hdr[26] | (hdr[27] << 8);
     const uint32_t comp = u32(28);
-    if (W < 1 || Hs == 0 || Hs == INT32_MIN || bpp != 24 || comp != 0 || (long long)W * (Hs < 0 ? -(long long)Hs : Hs) > (1LL << 26)) return RTP_EIO;
+    if (W < 1 || Hs == 0 || Hs == INT32_MIN || bpp != 24 || comp != 0 || (long long)W * (Hs < 0 ? -(long long)Hs : Hs) > (1LL << 26)) return rtp_internal_codec_fail(RTP_EIO, "BMP: only 24-bit uncompressed files up to 64 Mpixel are supported");
     const int H = Hs < 0 ? -Hs : Hs;
     *w = W; *h = H;
     if (!out_bgr) return RTP_OK;
@@ -260,7 +261,7 @@ int rtp_load_image(const char* path, unsigned char* out_bgr, size_t capacity, in
     f.seekg(data_off);
     for (int y = 0; y < H; ++y) {
       f.read((char*)row.data(), (std::streamsize)stride);
-      if (!f) return RTP_EIO;
+      if (!f) return rtp_internal_codec_fail(RTP_EIO, "BMP: truncated pixel data");
       const int dy = Hs < 0 ? y : H - 1 - y;
       memcpy(out_bgr + (size_t)dy * W * 3, row.data(), (size_t)W * 3);
     }

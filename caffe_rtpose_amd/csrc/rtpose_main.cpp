@@ -54,14 +54,17 @@ struct Flags {
   std::string precision = "fp16", model = "";  // --model coco|mpi: use the built-in graph + synthetic weights
   int frames_in_flight = 2, batch_frames = 1;
   unsigned long long synthetic_seed = 1;
+  std::string devices;           // "0,0,1": device of worker i (default start_device + i); lets two workers share one GPU
+  int test_worker_delay_ms = 0;  // test hook: every worker sleeps this long after a submit (provokes the >0.1 s frame drops)
 };
 
 int parse_flags(int argc, char** argv, Flags& F) {
   std::map<std::string, std::string*> sflags = {{"write_frames", &F.write_frames}, {"write_json", &F.write_json}, {"video", &F.video},
       {"image_dir", &F.image_dir}, {"caffemodel", &F.caffemodel}, {"caffeproto", &F.caffeproto}, {"resolution", &F.resolution},
-      {"net_resolution", &F.net_resolution}, {"camera_resolution", &F.camera_resolution}, {"precision", &F.precision}, {"model", &F.model}};
+      {"net_resolution", &F.net_resolution}, {"camera_resolution", &F.camera_resolution}, {"precision", &F.precision}, {"model", &F.model}, {"devices", &F.devices}};
   std::map<std::string, int*> iflags = {{"part_to_show", &F.part_to_show}, {"camera", &F.camera}, {"start_frame", &F.start_frame},
-      {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}, {"batch_frames", &F.batch_frames}};
+      {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}, {"batch_frames", &F.batch_frames},
+      {"test_worker_delay_ms", &F.test_worker_delay_ms}};
   std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}};
   std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"host_preprocess", &F.host_preprocess}, {"no_display", &F.no_display},
       {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}};
@@ -102,7 +105,8 @@ void usage() {
          "  --caffeproto FILE --caffemodel FILE   | --model coco|mpi (built-in graph, synthetic weights)\n"
          "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
          "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
-         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K --batch_frames B --host_preprocess]\n");
+         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K --batch_frames B --host_preprocess\n"
+         "   --devices d0,d1,.. (device of each worker; the same device may appear twice)]\n");
 }
 
 // ---- queues (caffe::BlockingQueue, util/blocking_queue.cpp:26-61) -----------------------------
@@ -146,6 +150,7 @@ struct Global {
   std::mutex mutex;
   std::atomic<bool> quit_threads{false};
   std::atomic<int> produced{0}, finished{0}, dropped{0};
+  std::vector<int> per_worker;  // frames each worker submitted (dynamic pull from the one shared queue)
   std::atomic<bool> producer_done{false};
   int num_parts = 18;
   std::vector<std::string> image_list;
@@ -236,7 +241,7 @@ void producer() {
 }
 
 // ---- per-GPU worker (processFrame, rtpose.cpp:1079-1203) -----------------------------------------
-void worker(int device, int* status) {
+void worker(int widx, int device, int* status) {
   rtp_config cfg;
   rtp_config_default(&cfg);
   cfg.device_id = device;
@@ -294,8 +299,15 @@ void worker(int device, int* status) {
                                         : rtp_submit_frame(e, fr.image.data(), fr.img_w, fr.img_h, (uint64_t)fr.index, &fr.scale);
       fr.image.clear();
       fr.image.shrink_to_fit();
-      if (src != RTP_OK) { fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(e)); *status = 1; break; }
+      if (src != RTP_OK) {  // nobody else may be left to drain the queue: stop the producer too
+        fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(e));
+        *status = 1;
+        G.quit_threads = true;
+        break;
+      }
+      G.per_worker[widx]++;
       inflight.push_back(std::move(fr));
+      if (F.test_worker_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(F.test_worker_delay_ms));
       if ((int)inflight.size() < F.frames_in_flight) continue;
     }
     if (!inflight.empty()) collect_one();
@@ -449,12 +461,30 @@ int main(int argc, char** argv) {
   for (const std::string* d : {&F.write_frames, &F.write_json})
     if (!d->empty() && !mkdir_p(*d)) { fprintf(stderr, "Could not write to or create directory %s\n", d->c_str()); return 1; }
   if (F.num_gpu < 1) { fprintf(stderr, "--num_gpu must be >= 1\n"); return 1; }
+  if (F.frames_in_flight < 1 || F.frames_in_flight > 64) { fprintf(stderr, "--frames_in_flight must be in [1, 64]\n"); return 1; }
+  if (F.batch_frames < 1 || F.batch_frames > 16) { fprintf(stderr, "--batch_frames must be in [1, 16]\n"); return 1; }
+  std::vector<int> devs;
+  for (int g = 0; g < F.num_gpu; ++g) devs.push_back(g + F.start_device);  // rtpose.cpp:1466
+  if (!F.devices.empty()) {
+    devs.clear();
+    size_t pos = 0;
+    while (pos <= F.devices.size()) {
+      const size_t c = F.devices.find(',', pos);
+      const std::string tok = F.devices.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+      if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) { fprintf(stderr, "bad --devices '%s'\n", F.devices.c_str()); return 1; }
+      devs.push_back(atoi(tok.c_str()));
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+    if ((int)devs.size() != F.num_gpu) { fprintf(stderr, "--devices names %zu devices but --num_gpu is %d\n", devs.size(), F.num_gpu); return 1; }
+  }
+  G.per_worker.assign(F.num_gpu, 0);
   if (!F.write_frames.empty() && F.host_preprocess) { fprintf(stderr, "--write_frames needs the device pre-processing path (drop --host_preprocess)\n"); return 1; }
 
   const double t0 = wall();
   std::vector<std::thread> workers;
   std::vector<int> status(F.num_gpu, 0);
-  for (int g = 0; g < F.num_gpu; ++g) workers.emplace_back(worker, g + F.start_device, &status[g]);
+  for (int g = 0; g < F.num_gpu; ++g) workers.emplace_back(worker, g, devs[g], &status[g]);
   std::atomic<bool> workers_done{false}, reorder_done{false};
   std::thread prod(producer), reo(reorderer, &workers_done), wr(writer, &reorder_done);
   std::vector<std::thread> encoders;
@@ -470,6 +500,7 @@ int main(int argc, char** argv) {
   int rc = 0;
   for (int s : status) rc |= s;
   const double dt = wall() - t0;
+  for (int g = 0; g < F.num_gpu; ++g) fprintf(stderr, "worker %d (GPU %d) processed %d frames\n", g, devs[g], G.per_worker[g]);
   fprintf(stderr, "rtcpm %s. Total time: %.3f seconds. frames produced %d, written %d, dropped %d (%.1f FPS incl. init)\n",
           rc ? "FAILED" : "successfully finished", dt, G.produced.load(), G.finished.load(), G.dropped.load(), G.finished.load() / dt);
   return rc;

@@ -41,6 +41,20 @@ def timed_region(run_fn, steps, warmup, dist=None, device_sync=None, reduce_devi
     return dt
 
 
+def scaled_steps(steps, est_steps_per_s, min_seconds, dist=None):
+    """Number of steps to time: at least `steps`, and enough for a timed region of `min_seconds` at the
+    estimated per-rank rate; every rank gets the same number (MAX over ranks)."""
+    import math
+    n = max(int(steps), int(math.ceil(min_seconds * max(est_steps_per_s, 0.0))))
+    if dist is not None:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([n], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = int(t.item())
+    return n
+
+
 def aggregate_fps(steps_per_rank, world, seconds):
     """Whole-job throughput: every rank processed steps_per_rank frames (weak scaling)."""
     return steps_per_rank * world / seconds

@@ -7,6 +7,7 @@ from ._lib import lib, rtp_config, fp, ip
 
 MODEL_COCO_18, MODEL_MPI_15 = 0, 1
 PREC_FP16, PREC_FP32 = 0, 1
+EXEC_GRAPH, EXEC_EAGER = 0, 1
 MAX_PEOPLE = 96
 
 

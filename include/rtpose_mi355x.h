@@ -42,6 +42,11 @@ extern "C" {
 #define RTP_PREC_FP16 0 /* fp16 storage, MFMA f16 with fp32 accumulate (headline path)      */
 #define RTP_PREC_FP32 1 /* fp32 storage, exact-f32 MFMA (parity path, 1/16 the MFMA rate)   */
 
+#define RTP_EXEC_GRAPH 0 /* default: the static launch plan of one batch (conv stack + every frame's  *
+                          * post-processing chain + D2H) is captured ONCE per (engine, frames in the  *
+                          * batch) into a hipGraph and replayed with one hipGraphLaunch per batch      */
+#define RTP_EXEC_EAGER 1 /* one HIP launch per kernel (diagnostics; per-stage event timing)            */
+
 #define RTP_MAX_PEOPLE 96    /* RENDER_MAX_PEOPLE, include/rtpose/renderFunctions.h:6 */
 #define RTP_MAX_NUM_PARTS 70 /* MAX_NUM_PARTS, rtpose.cpp:91                          */
 
@@ -69,6 +74,8 @@ typedef struct rtp_config {
                             * depend on B.  ceil(frames_in_flight / B) batches are in flight.       */
   int render;              /* 1: also draw the pose overlay on the display image (render_pose_*,   *
                             * renderFunctions.cu; part_to_show == 0) for rtp_collect_rendered        */
+  int exec_mode;           /* RTP_EXEC_*: how a batch's ~45 launches reach the GPU.  Replaces the  *
+                            * reference's per-call layer walk (net.cpp:544-556 ForwardFromTo).       */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
@@ -237,7 +244,8 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms_per_step, double* gflo
  * launch.  Used by bench.py for the roofline line. */
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch);
 /* In-situ timing of the dominant kernel class (every paired 7x7 128->128 launch of every frame):
- * enable = 1/0 switches it on/off (resetting the totals on a change), enable < 0 only reads.  While
+ * enable = 1/0 switches it on/off (resetting the totals on a change), 2 = on AND reset, enable < 0 only
+ * reads; the mode can only change on an idle engine (graph replays carry their own stamp slots).  While
  * on, each such launch records {first workgroup start, last workgroup end} of the device wall clock
  * (what a profiler's kernel trace reports; stream events would also count the time a launch queues
  * behind other frames' kernels).  Call with an idle engine to harvest. */

@@ -316,3 +316,52 @@ def test_bit_exact_kernels_contain_no_packed_f32_valu():
     assert out.returncode == 0, out.stderr
     counts = [int(x) for x in out.stdout.split()]
     assert counts == [0, 0, 0, 0, 0], out.stdout   # postproc, preproc, render, conv_ring, conv_igemm
+
+
+def test_caffemodel_blobshape_lengths_are_bounds_checked(tmp_path):
+    """A BlobShape whose packed-dims length runs past the message (heap over-read) is a parse
+    error, not a read beyond the file buffer; a well-formed new-style shape still loads."""
+    import caffe_rtpose_amd as r
+
+    def vi(v):
+        out = b""
+        while v >= 0x80:
+            out += bytes([(v & 0x7F) | 0x80])
+            v >>= 7
+        return out + bytes([v])
+
+    def field(fn, payload):
+        return vi((fn << 3) | 2) + vi(len(payload)) + payload
+
+    floats = np.arange(4, dtype="<f4").tobytes()
+    good_shape = field(1, bytes([1, 1, 2, 2]))                       # BlobShape.dim packed: 1x1x2x2
+    good = field(1, b"n") + field(100, field(1, b"c") + field(7, field(7, good_shape) + field(5, floats)))
+    p = tmp_path / "good.caffemodel"
+    open(p, "wb").write(good)
+    got = r.read_caffemodel_layers(p)
+    assert got[0]["name"] == "c" and got[0]["count0"] == 4
+    for bad_len in (0x7F, 0xFFFF, 1 << 40):
+        bad_shape = vi((1 << 3) | 2) + vi(bad_len) + bytes([1, 1])   # claims bad_len bytes of dims, has 2
+        bad = field(1, b"n") + field(100, field(1, b"c") + field(7, field(7, bad_shape) + field(5, floats)))
+        p = tmp_path / "bad.caffemodel"
+        open(p, "wb").write(bad)
+        with pytest.raises(r.RtpError):
+            r.read_caffemodel_layers(p)
+
+
+def test_prototxt_kernel_h_w_spelling(tmp_path):
+    """Caffe accepts kernel_size or the kernel_h/kernel_w pair; a square pair must parse, a non-square or
+    half-specified one is outside the linevec path."""
+    import caffe_rtpose_amd as r
+    src = tmp_path / "a.prototxt"
+    r.write_builtin_prototxt(r.MODEL_COCO_18, src)
+    text = open(src).read()
+    assert "kernel_size: 3" in text
+    sq = tmp_path / "sq.prototxt"
+    open(sq, "w").write(text.replace("kernel_size: 3", "kernel_h: 3 kernel_w: 3", 1))
+    assert r.prototxt_summary(sq) == r.prototxt_summary(src)
+    for bad in ("kernel_h: 3 kernel_w: 5", "kernel_h: 3", "kernel_w: 3"):
+        b = tmp_path / "bad.prototxt"
+        open(b, "w").write(text.replace("kernel_size: 3", bad, 1))
+        with pytest.raises(r.RtpError):
+            r.prototxt_summary(b)

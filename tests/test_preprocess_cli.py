@@ -242,3 +242,60 @@ def test_cli_reorderer_order_drops_and_window(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok ") == 5
+
+
+def test_cli_validates_pipeline_depth_flags():
+    """--frames_in_flight 0 used to hang (the worker never pops, the producer spins on back-pressure): now a flag error."""
+    for flag, val in (("--frames_in_flight", "0"), ("--batch_frames", "0"), ("--batch_frames", "99")):
+        p = subprocess.run([BIN, "--video", "synthetic:64x48:2", "--model", "coco", flag, val], capture_output=True, timeout=30)
+        assert p.returncode == 1 and flag[2:].encode() in p.stderr
+    p = subprocess.run([BIN, "--video", "synthetic:64x48:2", "--model", "coco", "--num_gpu", "2", "--devices", "0"], capture_output=True, timeout=30)
+    assert p.returncode == 1 and b"--devices" in p.stderr
+
+
+def _worker_counts(stderr):
+    import re
+    return [int(m.group(1)) for m in re.finditer(rb"worker \d+ \(GPU \d+\) processed (\d+) frames", stderr)]
+
+
+@pytest.mark.gpu
+def test_cli_two_workers_share_one_queue(tmp_path):
+    """--num_gpu 2 (both workers on device 0 through the --devices hook): two engines pull from the ONE input queue
+    (rtpose.cpp:1463-1472, 1107), every frame is written once, the JSON equals the one-worker run byte for byte."""
+    outs = []
+    for ngpu, extra in ((1, []), (2, ["--devices", "0,0"])):
+        out = tmp_path / f"js{ngpu}"
+        p = subprocess.run([BIN, "--video", "synthetic:640x480:24:7", "--model", "coco", "--net_resolution", "160x96", "--resolution", "320x240",
+                            "--write_json", str(out), "--no_frame_drops", "--no_display", "--num_gpu", str(ngpu)] + extra, capture_output=True, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()
+        counts = _worker_counts(p.stderr)
+        assert len(counts) == ngpu and sum(counts) == 24
+        if ngpu == 2:
+            assert min(counts) > 0, f"one worker never got a frame: {counts}"
+        outs.append(out)
+    files = sorted(os.listdir(outs[0]))
+    assert files == [f"frame{i:06d}.json" for i in range(24)] == sorted(os.listdir(outs[1]))
+    for f in files:
+        assert open(outs[0] / f, "rb").read() == open(outs[1] / f, "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_frame_drops_and_no_frame_drops(tmp_path):
+    """processFrame drops a frame that waited > 0.1 s for a GPU (rtpose.cpp:1112-1124) and the re-orderer skips its
+    index; --no_frame_drops disables that.  A slow worker (test hook: 60 ms per frame) makes the queue back up."""
+    import re
+    common = [BIN, "--video", "synthetic:320x240:40:3", "--model", "coco", "--net_resolution", "160x96", "--resolution", "320x240",
+              "--no_display", "--num_gpu", "1", "--frames_in_flight", "1", "--test_worker_delay_ms", "60"]
+    out = tmp_path / "drop"
+    p = subprocess.run(common + ["--write_json", str(out)], capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()
+    m = re.search(rb"frames produced (\d+), written (\d+), dropped (\d+)", p.stderr)
+    produced, written, dropped = (int(x) for x in m.groups())
+    assert produced == 40 and dropped > 0 and written + dropped == produced
+    assert len(os.listdir(out)) == written            # dropped frames leave no file; nothing is written twice
+    out2 = tmp_path / "nodrop"
+    p = subprocess.run(common + ["--write_json", str(out2), "--no_frame_drops"], capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()
+    m = re.search(rb"frames produced (\d+), written (\d+), dropped (\d+)", p.stderr)
+    assert tuple(int(x) for x in m.groups()) == (40, 40, 0)
+    assert sorted(os.listdir(out2)) == [f"frame{i:06d}.json" for i in range(40)]

@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""CPU simulation of storage-precision modes of the linevec conv stack (test tooling, torch CPU).
+
+Answers "which roundings cost how much of the final-map error": every layer is an fp32 conv2d
+(what fp16 x fp16 products with fp32 accumulation give, up to 1e-7) whose weights and/or input
+activations are first rounded the way a storage mode rounds them:
+  h  = one fp16 number                       (11 significant bits)
+  hh = hi + lo pair of fp16 numbers          (~22 bits: the split mode)
+  f  = fp32
+Usage: sim_precision.py [--w 160 --h 96] MODE...   with MODE = <weights>:<activations>[:<section-overrides>]
+e.g.   h:h   f:h   h:f   hh:h   h:h:s6=hh:hh  h:h:cat=hh
+"""
+import argparse
+import re
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C  # noqa: E402
+
+from caffe_rtpose_amd._lib import lib  # noqa: E402
+
+
+def synth(name, cout, cin, k, seed=1):
+    w = np.empty((cout, cin, k, k), np.float32)
+    b = np.empty((cout,), np.float32)
+    fp = C.POINTER(C.c_float)
+    lib.rtp_synth_weights(C.c_uint64(seed), name.encode(), cout, cin, k, w.ctypes.data_as(fp), b.ctypes.data_as(fp))
+    return torch.from_numpy(w), torch.from_numpy(b)
+
+
+def rnd(t, mode):
+    if mode == "f":
+        return t
+    hi = t.half().float()
+    if mode == "h":
+        return hi
+    lo = (t - hi).half().float()
+    return hi + lo
+
+
+def layers(model=0):
+    """(name, cin, cout, k, relu, section) in execution order + topology handled in forward()."""
+    nL1, nL2 = (38, 19) if model == 0 else (28, 16)
+    trunk = [("conv1_1", 3, 64), ("conv1_2", 64, 64), "pool", ("conv2_1", 64, 128), ("conv2_2", 128, 128), "pool",
+             ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), ("conv3_4", 256, 256), "pool",
+             ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3_CPM", 512, 256), ("conv4_4_CPM", 256, 128)]
+    return trunk, nL1, nL2
+
+
+def forward(x, wm, am, over, model=0):
+    trunk, nL1, nL2 = layers(model)
+
+    def conv(name, t, cin, cout, k, relu, sec):
+        w_mode, a_mode = over.get(sec, (wm, am))
+        for pat, v in over.items():
+            if pat.startswith("re/") and re.search(pat[3:], name):
+                w_mode, a_mode = v
+        w, b = synth(name, cout, cin, k)
+        y = F.conv2d(rnd(t, a_mode), rnd(w, w_mode), b, padding=k // 2)
+        return F.relu(y) if relu else y
+
+    t = x
+    for it in trunk:
+        if it == "pool":
+            t = F.max_pool2d(t, 2, 2)
+        else:
+            t = conv(it[0], t, it[1], it[2], 3, True, "trunk")
+    feat = t
+    outs = []
+    for br, n in ((1, nL1), (2, nL2)):
+        u = feat
+        for i in (1, 2, 3):
+            u = conv(f"conv5_{i}_CPM_L{br}", u, 128, 128, 3, True, "s1")
+        u = conv(f"conv5_4_CPM_L{br}", u, 128, 512, 1, True, "s1")
+        u = conv(f"conv5_5_CPM_L{br}", u, 512, n, 1, False, "s1")
+        outs.append(u)
+    for s in range(2, 7):
+        cat = torch.cat([outs[0], outs[1], feat], 1)
+        sec = f"s{s}"
+        new = []
+        for br, n in ((1, nL1), (2, nL2)):
+            u = cat
+            cin = cat.shape[1]
+            for i in range(1, 6):
+                # the concat re-injection can carry its own activation mode ("cat")
+                s_eff = "cat" if (i == 1 and "cat" in over) else sec
+                if s_eff == "cat":
+                    w_mode = over.get(sec, (wm, am))[0]
+                    w, b = synth(f"Mconv{i}_stage{s}_L{br}", 128, cin, 7)
+                    u = F.relu(F.conv2d(rnd(u, over["cat"][1]), rnd(w, w_mode), b, padding=3))
+                else:
+                    u = conv(f"Mconv{i}_stage{s}_L{br}", u, cin, 128, 7, True, sec)
+                cin = 128
+            u = conv(f"Mconv6_stage{s}_L{br}", u, 128, 128, 1, True, sec)
+            u = conv(f"Mconv7_stage{s}_L{br}", u, 128, n, 1, False, sec)
+            new.append(u)
+        outs = new
+    return torch.cat([outs[1], outs[0]], 1)  # concat_stage7: heat maps first
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--w", type=int, default=160)
+    ap.add_argument("--h", type=int, default=96)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("modes", nargs="+")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    rs = np.random.RandomState(a.seed)
+    x = torch.from_numpy((rs.randint(0, 256, size=(1, 3, a.h, a.w)).astype(np.float32) / 256.0 - 0.5))
+    with torch.no_grad():
+        ref = forward(x.double().float(), "f", "f", {})
+        mx = ref.abs().max().item()
+        print(f"ref {a.w}x{a.h}: max|ref| {mx:.3f} std {ref.std().item():.3f}")
+        for m in a.modes:
+            parts = m.split(":")
+            over = {}
+            for p in parts[2:]:
+                sec, v = p.split("=")
+                v = v.split(",")
+                over[sec] = (v[0], v[1] if len(v) > 1 else v[0])
+            out = forward(x, parts[0], parts[1], over)
+            err = (out - ref).abs()
+            print(f"{m:28s} max|err|/max|ref| {err.max().item() / mx:.3e}   rms/max {err.pow(2).mean().sqrt().item() / mx:.3e}")
+
+
+if __name__ == "__main__":
+    main()
