@@ -1,0 +1,36 @@
+#!/bin/bash
+# build_ref.sh — oracle/_ref/libref.so from the reference's OWN sources, compiled where they lie.
+# Needs /root/reference (this container only; the GPU box uses the prebuilt .so, which travels with gpurun).
+# Nothing from the reference tree is copied into the repository: the cut-out line ranges live under
+# oracle/_ref/gen/ only while this script runs.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${RTP_REFERENCE:-/root/reference}"
+OUT="$HERE/../_ref"
+[ -d "$REF" ] || { echo "build_ref.sh: $REF not present, nothing to build"; exit 0; }
+mkdir -p "$OUT/gen"
+RT="$REF/examples/rtpose/rtpose.cpp"
+IM="$REF/src/caffe/cpm/layers/imresize_layer.cu"
+NM="$REF/src/caffe/cpm/layers/nms_layer.cu"
+
+cut_range() {  # file first last expected-first-line-regex expected-last-line-regex output
+  local f="$1" a="$2" b="$3" ra="$4" rb="$5" o="$6"
+  sed -n "${a}p" "$f" | grep -Eq "$ra" || { echo "build_ref.sh: $f:$a does not match /$ra/ — the reference moved, fix the ranges"; exit 1; }
+  sed -n "${b}p" "$f" | grep -Eq "$rb" || { echo "build_ref.sh: $f:$b does not match /$rb/ — the reference moved, fix the ranges"; exit 1; }
+  sed -n "${a},${b}p" "$f" > "$OUT/gen/$o"
+}
+cut_range "$RT" 144 152 '^struct ColumnCompare' '^};' rtpose_144_152.inc
+cut_range "$RT" 239 269 '^void process_and_pad_image' '^}' rtpose_239_269.inc
+cut_range "$RT" 549 751 '^int connectLimbs\(' '^}' rtpose_549_751.inc
+cut_range "$RT" 808 1076 '^int connectLimbsCOCO\(' '^}' rtpose_808_1076.inc
+cut_range "$RT" 1383 1416 'FLAGS_write_json.empty' '^        }' rtpose_1383_1416.inc
+cut_range "$IM" 8 18 '^template <typename Dtype>' '^}' imresize_8_18.inc
+cut_range "$IM" 98 155 '^template <typename Dtype>' '^}' imresize_98_155.inc
+cut_range "$NM" 14 113 '^template <typename Dtype>' '^}' nms_14_113.inc
+
+CXX="${CXX:-g++}"
+# -ffp-contract=off and no -ffast-math: the floating point of the C++ source, nothing else
+FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -fno-fast-math -w -I$HERE -I$OUT -I$REF/include"
+$CXX $FLAGS -shared -o "$OUT/libref.so" "$HERE/ref_shim.cpp" "$REF/src/rtpose/modelDescriptor.cpp" "$REF/src/rtpose/modelDescriptorFactory.cpp"
+rm -rf "$OUT/gen"
+echo "built $OUT/libref.so"

@@ -24,10 +24,19 @@
 //       (src/caffe/test/test_pooling_layer.cpp:49-103, test_convolution_layer.cpp:21-139,
 //        :498-589, test_neuron_layer.cpp:208-221, test_concat_layer.cpp:143-167) — restated
 //       in tests/test_oracle_kat.py — and cross-checked against torch CPU conv2d.
-//   imresize / nms / connect / json / prep : **PARITY UNPINNED** — the reference ships no
-//       test, golden vector or sample output for anything CMU added, and it cannot be
-//       built here (no CUDA/OpenCV/protobuf/glog/boost).  These functions are line-by-line
-//       restatements of the cited sources; nothing independent confirms them.
+//   imresize / nms / connect / json / prep / tables : PINNED on the reference's OWN CODE:
+//       oracle/ref_recipe/build_ref.sh cuts connectLimbs, connectLimbsCOCO, process_and_pad_image,
+//       ColumnCompare and the --write_json block out of examples/rtpose/rtpose.cpp, and
+//       cubic_interpolation / imresize_cubic_kernel / nms_register_kernel / writeResultKernel out
+//       of the two .cu files (run on the host through cuda_emul.h), compiles them with
+//       modelDescriptor*.cpp against stub headers into oracle/_ref/libref.so, and
+//       tests/test_ref_pin.py requires this file == libref.so BIT FOR BIT on noise maps that
+//       saturate max_peaks, planted people 1/5/20, COCO + MPI, 1-3 scales, all-tied scores, stale
+//       slots, single-sided limbs and JSON edge values.  tests/golden/ref_pin.npz carries the
+//       reference's outputs to the GPU box (tools/make_ref_golden.py).
+//       Not reproduced by a host build: nvcc's default FMA contraction in the two kernels (the
+//       pinned semantics are those of the C++ source, -ffp-contract=off).
+//   The conv STACK as a whole (Caffe's Net + BLAS) cannot be built here; it rests on the KATs above.
 //
 // Build: see oracle/Makefile  (g++ -O2 -fopenmp -ffp-contract=off: source-level float
 // semantics, no FMA contraction, so every float op below rounds exactly where the

@@ -1,0 +1,109 @@
+"""Deterministic post-processing / host-function cases shared by
+  * tests/test_ref_pin.py      oracle == oracle/_ref (the reference's own code), bit for bit      [CPU, needs libref.so]
+  * tools/make_ref_golden.py   writes the _ref outputs to tests/golden/ref_pin.npz               [this container]
+  * tests/test_ref_golden.py   oracle == golden [CPU] and HIP engine == golden [GPU box, no /root/reference there]
+Inputs are regenerated from seeds (numpy RandomState), only OUTPUTS are stored."""
+import hashlib
+
+import numpy as np
+
+import _synth
+
+THR = {0: dict(nms_threshold=0.05, inter_threshold=0.05, inter_min_above=9, min_subset_cnt=3, min_subset_score=0.4),   # rtpose.cpp:218-226
+       1: dict(nms_threshold=0.2, inter_threshold=0.01, inter_min_above=8, min_subset_cnt=3, min_subset_score=0.4)}    # rtpose.cpp:212-217
+DIMS = {0: (18, 64, 57), 1: (15, 20, 44)}  # parts, max_peaks, heat channels
+
+
+def digest(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def lowres_cases(tables):
+    """name -> (model, lowres [N][C][h][w], net_w, net_h, start_scale, scale_gap)"""
+    c = {}
+    c["coco_noise_1s"] = (0, _synth.smooth_field(57, 46, 82, seed=3)[None], 656, 368, 1.0, 0.3)
+    c["coco_noise_3s"] = (0, _synth.smooth_field(3 * 57, 46, 82, seed=3).reshape(3, 57, 46, 82), 656, 368, 1.0, 0.15)
+    c["mpi_noise_1s"] = (1, _synth.smooth_field(44, 46, 62, seed=6)[None], 496, 368, 1.0, 0.3)
+    c["small_noise_2s"] = (0, _synth.smooth_field(2 * 57, 12, 20, seed=7).reshape(2, 57, 12, 20), 160, 96, 1.0, 0.25)
+    for P in (1, 5, 20):
+        c[f"coco_people{P}"] = (0, _synth.people_lowres(0, tables[0], P, 46, 82, seed=20 + P)[0], 656, 368, 1.0, 0.3)
+    c["coco_people5_3s"] = (0, _synth.people_lowres(0, tables[0], 5, 46, 82, seed=44, N=3)[0], 656, 368, 1.0, 0.15)
+    c["mpi_people5"] = (1, _synth.people_lowres(1, tables[1], 5, 46, 62, seed=25)[0], 496, 368, 1.0, 0.3)
+    return c
+
+
+def clamp_counts(peaks, max_peaks):
+    """The reference loops over nA/nB = peaks[part][0] slots although only max_peaks exist (rtpose.cpp:843,897 vs
+    nms_layer.cu:70,110): out of contract.  Oracle and engine clamp inside connect; the reference gets clamped counts."""
+    p = peaks.copy()
+    p[:, 0, 0] = np.minimum(p[:, 0, 0], max_peaks)
+    return p
+
+
+def chain(impl, model, low, net_w, net_h, start, gap, disp=(1280, 720)):
+    """ImResize -> Nms -> connect through `impl` (tests/_oracle.py or tests/_ref.py: same call shapes)."""
+    parts, max_peaks, _ = DIMS[model]
+    thr = THR[model]
+    res = impl.imresize(np.ascontiguousarray(low, np.float32), net_w, net_h, start, gap)[0]
+    peaks = impl.nms(res, parts, max_peaks, thr["nms_threshold"])
+    n, joints = impl.connect(model, res, clamp_counts(peaks, max_peaks), max_peaks, net_w, net_h, disp[0], disp[1], thr)
+    return res, peaks, n, joints[:n].copy()
+
+
+def tie_case():
+    """Constant PAF => every candidate ties at one score: the greedy result depends on std::sort's order of equals."""
+    H, W = 368, 656
+    res = np.zeros((57, H, W), np.float32)
+    res[19:] = 0.70710677
+    rs = np.random.RandomState(11)
+    peaks = np.zeros((18, 65, 3), np.float32)
+    for p in range(18):
+        n = int(rs.randint(3, 30))
+        peaks[p, 0, 0] = n
+        base = rs.uniform(20, 200)
+        for i in range(1, n + 1):
+            peaks[p, i] = (base + 9 * i + p * 3, base * 0.5 + 9 * i + p * 3, rs.uniform(0.3, 0.9))
+    return res, peaks
+
+
+def single_sided_case():
+    res = np.zeros((57, 368, 656), np.float32)
+    peaks = np.zeros((18, 65, 3), np.float32)
+    peaks[1, 0, 0] = 2
+    peaks[1, 1] = (100, 100, 0.9)
+    peaks[1, 2] = (300, 120, 0.8)
+    peaks[0, 0, 0] = 1          # a nose with no neck candidate on limb (1,0): nA != 0, nB != 0 on that limb only
+    peaks[0, 1] = (110, 60, 0.7)
+    return res, peaks
+
+
+def stale_peaks(parts, max_peaks, seed=9):
+    rs = np.random.RandomState(seed)
+    return rs.uniform(-5, 5, size=(parts, max_peaks + 1, 3)).astype(np.float32)
+
+
+def json_cases():
+    rs = np.random.RandomState(13)
+    out = []
+    for model, n in ((0, 0), (0, 1), (0, 7), (1, 3)):
+        parts = DIMS[model][0]
+        j = rs.uniform(0, 1300, size=(max(n, 1), parts, 3)).astype(np.float32)
+        j[..., 2] = rs.uniform(0, 1, size=j.shape[:2])
+        if n:
+            j[0, 0] = (0.0, 0.0, 0.0)
+            j[0, 1] = (1e-7, 123456.789, 1.0)
+            j[-1, -1] = (1234.5678, 0.000123456, 0.99999994)
+        for scale in (1.0, 1.5, 0.5625, 2.0 / 3.0):
+            out.append((model, n, j[:n], np.float32(scale)))
+    return out
+
+
+def pad_cases():
+    rs = np.random.RandomState(17)
+    out = []
+    for (ow, oh, tw, th) in ((656, 368, 656, 368), (560, 320, 656, 368), (33, 17, 48, 32), (1, 1, 16, 16)):
+        img = rs.randint(0, 256, size=(oh, ow, 3)).astype(np.uint8)
+        for normalize in (0, 1):
+            out.append((img, tw, th, normalize))
+    return out

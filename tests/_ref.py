@@ -1,0 +1,92 @@
+"""ctypes binding of oracle/_ref/libref.so — the REFERENCE'S OWN code (connectLimbs*, process_and_pad_image, the JSON
+block, modelDescriptorFactory, and the ImResize / NMS CUDA kernels run as host C++), built by oracle/ref_recipe/build_ref.sh
+from /root/reference.  TEST INFRASTRUCTURE ONLY: it pins oracle/rtpose_oracle.cpp (tests/test_ref_pin.py) and produces
+tests/golden/ref_pin.npz (tools/make_ref_golden.py).  Nothing in the product may load it."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+_lib = None
+fp = C.POINTER(C.c_float)
+
+
+def available():
+    return os.path.exists(SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(SO)
+        _lib.ref_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _f(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(fp)
+
+
+def _chk(rc):
+    if rc < 0:
+        raise RuntimeError("reference CHECK failed: " + lib().ref_last_error().decode())
+    return rc
+
+
+def model_tables(model):
+    npart, nlimb = C.c_int(), C.c_int()
+    limb, mp = (C.c_int * 64)(), (C.c_int * 64)()
+    _chk(lib().ref_model_tables(model, C.byref(npart), C.byref(nlimb), limb, mp))
+    n = nlimb.value * 2
+    return npart.value, nlimb.value, list(limb)[:n], list(mp)[:n]
+
+
+def process_and_pad_image(img_u8, tw, th, normalize):
+    oh, ow, _ = img_u8.shape
+    img = np.ascontiguousarray(img_u8, np.uint8)
+    out = np.full((3, th, tw), np.nan, np.float32)
+    _chk(lib().ref_process_and_pad_image(_f(out), img.ctypes.data_as(C.POINTER(C.c_ubyte)), ow, oh, tw, th, int(normalize)))
+    return out
+
+
+def imresize(src, tw, th, start_scale=1.0, scale_gap=0.3):
+    num, Cc, h, w = src.shape
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.full((1, Cc, th, tw), np.nan, np.float32)
+    _chk(lib().ref_imresize(_f(src), num, Cc, h, w, tw, th, C.c_float(start_scale), C.c_float(scale_gap), _f(dst)))
+    return dst
+
+
+def nms(resized, num_parts, max_peaks, threshold, peaks_init=None):
+    Cc, H, W = resized.shape[-3:]
+    r = np.ascontiguousarray(resized.reshape(Cc, H, W), np.float32)
+    peaks = np.zeros((num_parts, max_peaks + 1, 3), np.float32) if peaks_init is None else np.ascontiguousarray(peaks_init, np.float32).copy()
+    _chk(lib().ref_nms(_f(r), H, W, num_parts, max_peaks, C.c_float(threshold), _f(peaks)))
+    return peaks
+
+
+def connect(model, resized, peaks, max_peaks, net_w, net_h, disp_w, disp_h, thr, max_people=96):
+    num_parts = 18 if model == 0 else 15
+    r = np.ascontiguousarray(resized, np.float32)
+    p = np.ascontiguousarray(peaks, np.float32)
+    joints = np.zeros((max_people, num_parts, 3), np.float32)
+    cnt = _chk(lib().ref_connect(model, _f(r), _f(p), max_peaks, net_w, net_h, disp_w, disp_h, C.c_float(thr["inter_threshold"]),
+                                 thr["inter_min_above"], thr["min_subset_cnt"], C.c_float(thr["min_subset_score"]), _f(joints)))
+    return cnt, joints
+
+
+def write_json(tmpdir, joints, num_people, model, frame_scale, frame_number=7, image_path=None):
+    j = np.ascontiguousarray(joints, np.float32).reshape(-1)
+    if j.size == 0:
+        j = np.zeros(3, np.float32)
+    _chk(lib().ref_write_json(str(tmpdir).encode(), image_path.encode() if image_path else None, frame_number, model, _f(j), num_people,
+                              C.c_float(frame_scale)))
+    if image_path:
+        stem = os.path.splitext(os.path.basename(image_path))[0]
+        name = f"{stem}.json"
+    else:
+        name = f"frame{frame_number:06d}.json"
+    return name, open(os.path.join(str(tmpdir), name), "rb").read()

@@ -1,0 +1,96 @@
+"""tests/golden/ref_pin.npz holds what the REFERENCE'S OWN CODE (oracle/_ref, built from /root/reference by
+oracle/ref_recipe/build_ref.sh; fixture written by tools/make_ref_golden.py) returns on the seeded cases of _pincases.py.
+  * CPU: the oracle reproduces every stored output bit for bit (also where libref.so is absent);
+  * GPU: the HIP engine, through the C-ABI, reproduces them — directly against the reference's outputs, no oracle in
+    between: ImResize / Nms / connect taps AND the production path that never materialises the resized map."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _pincases as pc
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_pin.npz"))
+
+
+def _tables():
+    t = {}
+    for m in (0, 1):
+        a = G[f"tables_{m}"].tolist()
+        nl = a[1]
+        t[m] = (a[0], nl, a[2:2 + 2 * nl], a[2 + 2 * nl:2 + 4 * nl])
+    return t
+
+
+def _sha(name):
+    return G[name].tobytes().decode()
+
+
+def test_oracle_reproduces_the_reference_outputs():
+    tables = _tables()
+    for m in (0, 1):
+        assert orc.model_tables(m) == tables[m]
+    for name, (model, low, W, H, start, gap) in pc.lowres_cases(tables).items():
+        res, peaks, n, joints = pc.chain(orc, model, low, W, H, start, gap)
+        assert pc.digest(res) == _sha(f"chain_{name}_resized_sha"), name
+        assert np.array_equal(peaks, G[f"chain_{name}_peaks"]), name
+        assert np.array_equal(joints, G[f"chain_{name}_joints"]), name
+    for nm, (res, peaks) in (("ties", pc.tie_case()), ("single", pc.single_sided_case())):
+        n, joints = orc.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
+        assert np.array_equal(joints[:n], G[f"connect_{nm}_joints"])
+    for i, (model, n, joints, scale) in enumerate(pc.json_cases()):
+        parts = pc.DIMS[model][0]
+        assert orc.write_json(joints if n else np.zeros((1, parts, 3), np.float32), n, parts, float(scale)) == G[f"json_{i}"].tobytes()
+    for i, (img, tw, th, normalize) in enumerate(pc.pad_cases()):
+        assert pc.digest(orc.process_and_pad_image(img, tw, th, normalize)) == _sha(f"pad_{i}_sha")
+
+
+def test_host_library_reproduces_the_reference_outputs():
+    """The product's host functions (no GPU needed): model tables, process_and_pad_image, JSON writer."""
+    import caffe_rtpose_amd as r
+    tables = _tables()
+    for m in (0, 1):
+        assert r.model_tables(m) == tables[m]
+    for i, (model, n, joints, scale) in enumerate(pc.json_cases()):
+        assert r.format_json(joints, n, pc.DIMS[model][0], float(scale)) == G[f"json_{i}"].tobytes()
+    for i, (img, tw, th, normalize) in enumerate(pc.pad_cases()):
+        assert pc.digest(r.process_and_pad_image(img, tw, th, normalize)) == _sha(f"pad_{i}_sha")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["coco_noise_1s", "coco_noise_3s", "mpi_noise_1s", "small_noise_2s", "coco_people1", "coco_people5",
+                                  "coco_people20", "coco_people5_3s", "mpi_people5"])
+def test_engine_reproduces_the_reference_outputs(name):
+    import caffe_rtpose_amd as r
+    model, low, W, H, start, gap = pc.lowres_cases(_tables())[name]
+    N = low.shape[0]
+    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, frames_in_flight=1))
+    low = np.ascontiguousarray(low, np.float32)
+    want_peaks, want_joints = G[f"chain_{name}_peaks"], G[f"chain_{name}_joints"]
+    # taps through the materialised map (the reference's own dataflow)
+    res = e.resize(low)
+    assert pc.digest(res) == _sha(f"chain_{name}_resized_sha")
+    assert np.array_equal(res.reshape(-1)[::997], G[f"chain_{name}_resized_sample"])
+    peaks = e.nms(res)
+    assert np.array_equal(peaks, want_peaks)
+    n, joints = e.connect(res, peaks)
+    assert n == len(want_joints) and np.array_equal(joints[:n], want_joints)
+    # production path: peaks and PAF samples straight from the low-res maps
+    p2, j2, n2 = e.post_from_lowres(low)
+    assert np.array_equal(p2, want_peaks) and n2 == len(want_joints) and np.array_equal(j2, want_joints)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_engine_connect_ties_stale_slots_vs_reference_outputs():
+    import caffe_rtpose_amd as r
+    e = r.Engine(r.Config(frames_in_flight=1))
+    for nm, (res, peaks) in (("ties", pc.tie_case()), ("single", pc.single_sided_case())):
+        n, joints = e.connect(res, peaks)
+        want = G[f"connect_{nm}_joints"]
+        assert n == len(want) and np.array_equal(joints[:n], want)
+    model, low, W, H, start, gap = pc.lowres_cases(_tables())["coco_people5"]
+    res = e.resize(np.ascontiguousarray(low, np.float32))
+    assert np.array_equal(e.nms(res, pc.stale_peaks(18, 64)), G["nms_stale_peaks"])
+    e.close()

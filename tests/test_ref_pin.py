@@ -1,0 +1,87 @@
+"""Pins oracle/rtpose_oracle.cpp (the CPU restatement every GPU parity test compares against) on the REFERENCE'S OWN
+CODE: oracle/_ref/libref.so = connectLimbs / connectLimbsCOCO / process_and_pad_image / the --write_json block /
+ModelDescriptorFactory compiled from /root/reference, and imresize_cubic_kernel / nms_register_kernel /
+writeResultKernel compiled from the .cu files and run on the host (oracle/ref_recipe/).  Bit-for-bit on every case.
+
+Runs where /root/reference exists (this container: __graft_entry__.build() builds libref.so).  The GPU box has no
+reference tree: there the same outputs come from tests/golden/ref_pin.npz (tests/test_ref_golden.py)."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _pincases as pc
+import _ref
+
+pytestmark = pytest.mark.skipif(not _ref.available(), reason="oracle/_ref/libref.so not built (needs /root/reference)")
+
+
+def test_model_tables_are_the_factorys():
+    for model in (0, 1):
+        assert orc.model_tables(model) == _ref.model_tables(model)
+
+
+def test_process_and_pad_image_bit_equal():
+    for img, tw, th, normalize in pc.pad_cases():
+        assert np.array_equal(orc.process_and_pad_image(img, tw, th, normalize), _ref.process_and_pad_image(img, tw, th, normalize))
+    with pytest.raises(RuntimeError, match="too big"):   # CHECK_GE(padw, 0) << "Image too big for target size."
+        _ref.process_and_pad_image(np.zeros((40, 40, 3), np.uint8), 32, 48, 1)
+
+
+@pytest.fixture(scope="module")
+def tables():
+    return {m: _ref.model_tables(m) for m in (0, 1)}
+
+
+def test_imresize_nms_connect_chain_bit_equal(tables):
+    """noise maps (peaks saturate max_peaks), planted people 1/5/20, COCO + MPI, 1-3 scales: every stage output equal."""
+    for name, (model, low, W, H, start, gap) in pc.lowres_cases(tables).items():
+        a = pc.chain(orc, model, low, W, H, start, gap)
+        b = pc.chain(_ref, model, low, W, H, start, gap)
+        assert np.array_equal(a[0], b[0]), f"{name}: ImResize differs"
+        assert np.array_equal(a[1], b[1]), f"{name}: Nms differs"
+        assert a[2] == b[2] and np.array_equal(a[3], b[3]), f"{name}: connect differs ({a[2]} vs {b[2]} people)"
+        if "people" in name:
+            assert a[2] >= 1, name
+
+
+def test_nms_stale_slots_and_count_semantics(tables):
+    """Slots beyond the peak count keep their previous contents; slot 0 holds the UNCLAMPED total (nms_layer.cu:110)."""
+    model, low, W, H, start, gap = pc.lowres_cases(tables)["coco_people5"]
+    res = _ref.imresize(low, W, H, start, gap)[0]
+    init = pc.stale_peaks(18, 64)
+    a, b = orc.nms(res, 18, 64, 0.05, init), _ref.nms(res, 18, 64, 0.05, init)
+    assert np.array_equal(a, b)
+    n = int(b[3, 0, 0])
+    assert 0 < n < 64 and np.array_equal(b[3, n + 1:], init[3, n + 1:])
+    noise = pc.lowres_cases(tables)["coco_noise_1s"]
+    pk = _ref.nms(_ref.imresize(noise[1], 656, 368, 1.0, 0.3)[0], 18, 64, 0.05)
+    assert pk[:, 0, 0].max() > 64          # saturated: more maxima than slots, count not clamped
+
+
+def test_connect_ties_and_single_sided_bit_equal():
+    for res, peaks in (pc.tie_case(), pc.single_sided_case()):
+        a = orc.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
+        b = _ref.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
+        assert a[0] == b[0] and np.array_equal(a[1][:a[0]], b[1][:b[0]])
+    assert orc.connect(0, *pc.tie_case(), 64, 656, 368, 1280, 720, pc.THR[0])[0] >= 1
+
+
+def test_connect_out_of_range_sample_is_a_check_failure():
+    """COCO: CHECK_GE(mx, 0) (rtpose.cpp:928) — the reference aborts; engine and oracle report RTP_ERANGE / -1."""
+    res = np.zeros((57, 368, 656), np.float32)
+    peaks = np.zeros((18, 65, 3), np.float32)
+    peaks[1, 0, 0] = peaks[2, 0, 0] = 1
+    peaks[1, 1] = (-30.0, 50.0, 0.9)
+    peaks[2, 1] = (40.0, 60.0, 0.9)
+    with pytest.raises(RuntimeError, match="mx >= 0"):
+        _ref.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
+
+
+def test_json_bytes_equal(tmp_path):
+    for i, (model, n, joints, scale) in enumerate(pc.json_cases()):
+        parts = pc.DIMS[model][0]
+        name, ref_bytes = _ref.write_json(tmp_path, joints, n, model, float(scale), frame_number=i)
+        assert name == f"frame{i:06d}.json"
+        assert orc.write_json(joints if n else np.zeros((1, parts, 3), np.float32), n, parts, float(scale)) == ref_bytes
+    name, _ = _ref.write_json(tmp_path, np.zeros((1, 18, 3), np.float32), 0, 0, 1.0, frame_number=0, image_path="/data/imgs/COCO_val_0001.jpg")
+    assert name == "COCO_val_0001.json"       # <stem>.json for --image_dir (rtpose.cpp:1390-1393)

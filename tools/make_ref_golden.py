@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""tests/golden/ref_pin.npz: outputs of the REFERENCE'S OWN code (oracle/_ref/libref.so, built by
+oracle/ref_recipe/build_ref.sh from /root/reference) on the seeded cases of tests/_pincases.py.
+Run in this container (needs /root/reference); the fixture travels to the GPU box, the reference does not.
+Big arrays (the 55 MB resized map) are stored as sha256 + a strided sample; peaks / joints / JSON in full."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _pincases as pc  # noqa: E402
+import _ref  # noqa: E402
+
+assert _ref.available(), "build oracle/_ref first: bash oracle/ref_recipe/build_ref.sh"
+out = {}
+tables = {m: _ref.model_tables(m) for m in (0, 1)}
+for m in (0, 1):
+    out[f"tables_{m}"] = np.array([tables[m][0], tables[m][1]] + tables[m][2] + tables[m][3], np.int32)
+for name, (model, low, W, H, start, gap) in pc.lowres_cases(tables).items():
+    res, peaks, n, joints = pc.chain(_ref, model, low, W, H, start, gap)
+    out[f"chain_{name}_resized_sha"] = np.frombuffer(pc.digest(res).encode(), np.uint8)
+    out[f"chain_{name}_resized_sample"] = res.reshape(-1)[::997].copy()
+    out[f"chain_{name}_peaks"] = peaks
+    out[f"chain_{name}_joints"] = joints
+    print(f"{name}: {n} people, peak totals max {int(peaks[:, 0, 0].max())}")
+for nm, (res, peaks) in (("ties", pc.tie_case()), ("single", pc.single_sided_case())):
+    n, joints = _ref.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
+    out[f"connect_{nm}_joints"] = joints[:n].copy()
+    print(f"connect {nm}: {n} people")
+model, low, W, H, start, gap = pc.lowres_cases(tables)["coco_people5"]
+out["nms_stale_peaks"] = _ref.nms(_ref.imresize(low, W, H, start, gap)[0], 18, 64, 0.05, pc.stale_peaks(18, 64))
+with tempfile.TemporaryDirectory() as d:
+    for i, (model, n, joints, scale) in enumerate(pc.json_cases()):
+        out[f"json_{i}"] = np.frombuffer(_ref.write_json(d, joints, n, model, float(scale), frame_number=i)[1], np.uint8)
+for i, (img, tw, th, normalize) in enumerate(pc.pad_cases()):
+    out[f"pad_{i}_sha"] = np.frombuffer(pc.digest(_ref.process_and_pad_image(img, tw, th, normalize)).encode(), np.uint8)
+path = os.path.join(ROOT, "tests", "golden", "ref_pin.npz")
+np.savez_compressed(path, **out)
+print(f"wrote {path}: {os.path.getsize(path)} bytes, {len(out)} arrays")
