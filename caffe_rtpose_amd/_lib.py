@@ -33,6 +33,7 @@ class rtp_config(C.Structure):
         ("batch_frames", C.c_int),
         ("render", C.c_int),
         ("exec_mode", C.c_int),
+        ("split_layers", C.c_char_p),
     ]
 
 

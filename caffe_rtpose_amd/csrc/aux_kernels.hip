@@ -55,7 +55,7 @@ hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, 
 // ---- 2x2 / stride 2 MAX pooling (pooling_layer.cpp:140-180; resolutions are even) ----------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, Geom gi, int Cpi, T* __restrict__ out,
-                                                       Geom go, int Cpo, int C) {
+                                                       Geom go, int Cpo, int C, int lo_i, int lo_o) {
   constexpr int VEC = 16 / sizeof(T);
   const int cv = C / VEC;
   const long total = (long)go.N * go.H * go.W * cv;
@@ -67,44 +67,69 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
     const int y = (int)(p % go.H);
     const int n = (int)(p / go.H);
     const T* ip = in + (((long)n * gi.Hp + 2 * y + gi.halo) * gi.Wp + 2 * x + gi.halo) * Cpi + c;
-    uint4 q00 = *(const uint4*)ip;
-    uint4 q01 = *(const uint4*)(ip + Cpi);
-    uint4 q10 = *(const uint4*)(ip + (long)gi.Wp * Cpi);
-    uint4 q11 = *(const uint4*)(ip + (long)gi.Wp * Cpi + Cpi);
-    T a[VEC], b[VEC], cc[VEC], d[VEC], o[VEC];
-    __builtin_memcpy(a, &q00, 16);
-    __builtin_memcpy(b, &q01, 16);
-    __builtin_memcpy(cc, &q10, 16);
-    __builtin_memcpy(d, &q11, 16);
+    const long offs[4] = {0, Cpi, (long)gi.Wp * Cpi, (long)gi.Wp * Cpi + Cpi};
+    T h[4][VEC], o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      T m = a[i];
-      m = b[i] > m ? b[i] : m;
-      m = cc[i] > m ? cc[i] : m;
-      m = d[i] > m ? d[i] : m;
-      o[i] = m;
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = *(const uint4*)(ip + offs[q]);
+      __builtin_memcpy(h[q], &v, 16);
+    }
+    T* op = out + (((long)n * go.Hp + y + go.halo) * go.Wp + x + go.halo) * Cpo + c;
+    if (!lo_i) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        T m = h[0][i];
+        m = h[1][i] > m ? h[1][i] : m;
+        m = h[2][i] > m ? h[2][i] : m;
+        m = h[3][i] > m ? h[3][i] : m;
+        o[i] = m;
+      }
+    } else {  // split precision: the value is hi + lo; the first maximum in (0,0),(0,1),(1,0),(1,1) order keeps both parts
+      T l[4][VEC], ol[VEC];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = *(const uint4*)(ip + offs[q] + lo_i);
+        __builtin_memcpy(l[q], &v, 16);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        T mh = h[0][i], ml = l[0][i];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const bool gt = h[q][i] > mh || (h[q][i] == mh && l[q][i] > ml);
+          mh = gt ? h[q][i] : mh;
+          ml = gt ? l[q][i] : ml;
+        }
+        o[i] = mh;
+        ol[i] = ml;
+      }
+      if (lo_o) {
+        uint4 rl;
+        __builtin_memcpy(&rl, ol, 16);
+        *(uint4*)(op + lo_o) = rl;
+      }
     }
     uint4 r;
     __builtin_memcpy(&r, o, 16);
-    *(uint4*)(out + (((long)n * go.Hp + y + go.halo) * go.Wp + x + go.halo) * Cpo + c) = r;
+    *(uint4*)op = r;
   }
 }
 
-hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C,
+hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o,
                           hipStream_t stream) {
   const int vec = prec == 0 ? 8 : 4;
   const long total = (long)go.N * go.H * go.W * (C / vec);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C);
-  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C);
+  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, lo_i, lo_o);
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C, lo_i, lo_o);
   return hipGetLastError();
 }
 
 // ---- debug export: halo'd NHWC -> planar fp32 NCHW (Net::blob_by_name()->cpu_data() tap) ----
 template <typename T>
 __global__ __launch_bounds__(256) void export_kernel(const T* __restrict__ in, Geom g, int Cp, const int* __restrict__ chmap,
-                                                      int C, float* __restrict__ out) {
+                                                      int C, int lo_off, float* __restrict__ out) {
   const long total = (long)g.N * C * g.H * g.W;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int x = (int)(idx % g.W);
@@ -114,17 +139,18 @@ __global__ __launch_bounds__(256) void export_kernel(const T* __restrict__ in, G
     const int c = (int)(p % C);
     const int n = (int)(p / C);
     const int ci = chmap ? chmap[c] : c;
-    out[idx] = (float)in[(((long)n * g.Hp + y + g.halo) * g.Wp + x + g.halo) * Cp + ci];
+    const T* ip = in + (((long)n * g.Hp + y + g.halo) * g.Wp + x + g.halo) * Cp + ci;
+    out[idx] = lo_off ? (float)ip[0] + (float)ip[lo_off] : (float)ip[0];
   }
 }
 
-hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, float* out,
+hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, int lo_off, float* out,
                          hipStream_t stream) {
   const long total = (long)g.N * C * g.H * g.W;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (prec == 0) hipLaunchKernelGGL(export_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, g, Cp, chmap_dev, C, out);
-  else hipLaunchKernelGGL(export_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, g, Cp, chmap_dev, C, out);
+  if (prec == 0) hipLaunchKernelGGL(export_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, g, Cp, chmap_dev, C, lo_off, out);
+  else hipLaunchKernelGGL(export_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, g, Cp, chmap_dev, C, lo_off, out);
   return hipGetLastError();
 }
 

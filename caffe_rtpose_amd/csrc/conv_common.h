@@ -115,7 +115,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
     const long pix = img_pix0 + m;
     for (int d = 0; d < pr.ndst; ++d) {
       T* dp = (T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].coff + c0;
-      if (nvalid == 16 && (((size_t)dp) & 15) == 0) {
+      const bool vec_ok = nvalid == 16 && (((size_t)dp) & 15) == 0;
+      if (vec_ok) {
 #pragma unroll
         for (int u = 0; u < 16 / VEC; ++u) {
           uint4 pk;
@@ -124,6 +125,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
         }
       } else {
         for (int u = 0; u < nvalid; ++u) dp[u] = out[u];
+      }
+      if (pr.dst[d].lo_off) {  // split-precision consumer: the rounding error of the stored value, as a second T
+        T lo[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lo[u] = (T)(v[u] - (float)out[u]);
+        T* lp = dp + pr.dst[d].lo_off;
+        if (vec_ok && (((size_t)lp) & 15) == 0) {
+#pragma unroll
+          for (int u = 0; u < 16 / VEC; ++u) {
+            uint4 pk;
+            __builtin_memcpy(&pk, &lo[u * VEC], 16);
+            ((uint4*)lp)[u] = pk;
+          }
+        } else {
+          for (int u = 0; u < nvalid; ++u) lp[u] = lo[u];
+        }
       }
     }
     if (pr.out_nchw) {

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams P) {
 
   // step = (r, chunk, s); the strip depends on (r, chunk) only
   auto load_a = [&](int r, int chunk) {
-    const unsigned char* p = in_base + (long)r * P.Wp * pix_bytes + (long)chunk * ROWB;
+    const int pchunk = (P.wrap_at && chunk >= P.wrap_at) ? chunk - P.wrap_at : chunk;  // split precision: see ConvParams::nchunk
+    const unsigned char* p = in_base + (long)r * P.Wp * pix_bytes + (long)pchunk * ROWB;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       if (a_ok[i]) ra[i] = *(const uint4*)(p + a_off_g[i]);

@@ -171,7 +171,11 @@ constexpr int ring_wait_count(int s) {
 // the LDS-DMA (and wait for it, counted); waves 0..3 only ds_read + MFMA (+ the epilogue).  The
 // in-order VMEM issue of a wave (~50 cycles per 1 KiB piece, 3-5 pieces per tap) then no longer sits
 // in front of the same wave's MFMAs.  Same LDS image, same wait counts, one barrier per tap for all.
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC>
+// VAR (experiments on the wave-specialised consumer loop, selected by ConvParams::variant; 0 = production):
+//   1 = all ds_reads of the next tap are issued during the FIRST half of the tap's MFMAs (2 per MFMA), so their LDS
+//       latency is covered by the second half instead of being waited for in front of the barrier
+//   ablations (wrong results, timing only): 11 = no ds_reads, 12 = no MFMAs, 13 = no LDS-DMA
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0>
 __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvParams P) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     else if constexpr (A_PW <= 8) { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<A_PW - 4>(a_ptr, a_voff + 4, l + 4096); }
     else { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<4>(a_ptr, a_voff + 4, l + 4096); dma_group_each<A_PW - 8>(a_ptr, a_voff + 8, l + 8192); }
     // past the last strip this keeps walking: harmless dummy reads of arena memory (tail pad)
-    if (++a_chunk == nchunk) { a_chunk = 0; a_ptr += row_step_bytes - (long)(nchunk - 1) * CHB; }
+    if (++a_chunk == nchunk) { a_chunk = 0; a_ptr += row_step_bytes - (long)P.last_phys * CHB; }
+    else if (a_chunk == P.wrap_at) a_ptr -= (long)(P.wrap_at - 1) * CHB;  // split precision: the a_hi chunks once more (x W_lo)
     else a_ptr += CHB;
   };
   auto issue_b = [&](int stage) {  // tile at b_ptr -> sB[stage]; advances b_ptr
@@ -303,8 +308,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
         wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (s == 0) { abuf ^= 1; issue_a(abuf ^ 1); }
-        issue_b(ist);
+        if constexpr (VAR != 13) {
+          if constexpr (s == 0) { abuf ^= 1; issue_a(abuf ^ 1); }
+          issue_b(ist);
+        }
         ist = (ist + 1 == SB) ? 0 : ist + 1;
       };
       pstep(std::integral_constant<int, 1>{}, std::true_type{});
@@ -354,12 +361,20 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < NMMA_C; ++m) {
-        {
+        if constexpr (VAR != 12) {
           const int gi = m / (TM * TN), r = m % (TM * TN);
           Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
         }
+        if constexpr (VAR == 1) {  // reads front-loaded: 2 per MFMA over the first half of the tap
+          constexpr int HALF = NMMA_C / 2 > 0 ? NMMA_C / 2 : 1;
+          if (m < HALF) {
 #pragma unroll
-        for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rd, pa, pb, aswz);
+            for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(rd, pa, pb, aswz);
+          }
+        } else if constexpr (VAR != 11) {
+#pragma unroll
+          for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rd, pa, pb, aswz);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       st = (st + 1 == SB) ? 0 : st + 1;
@@ -485,19 +500,31 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0>
 static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream);
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
-  if (P.spec) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true>(P, nprob, N, stream);
+  if (P.spec) {
+    // experiment variants exist for the dominant plan only (fp16, 7x7, tile 128x64, 256-byte chunks)
+    if constexpr (std::is_same<T, _Float16>::value && BM == 128 && BN == 64 && KS == 7 && CHB == 256) {
+      switch (P.variant) {
+        case 1: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 1>(P, nprob, N, stream);
+        case 11: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 11>(P, nprob, N, stream);
+        case 12: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 12>(P, nprob, N, stream);
+        case 13: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 13>(P, nprob, N, stream);
+        default: break;
+      }
+    }
+    return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true>(P, nprob, N, stream);
+  }
   return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, false>(P, nprob, N, stream);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR>
 static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
-  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC>;
+  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC, VAR>;
   static std::atomic<unsigned> attr_mask{0};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -46,6 +46,9 @@ struct Tensor {
   int C = 0, Cp = 0, level = 0;
   size_t offset = 0;        // byte offset of padded pixel 0 of image 0 inside a context arena
   std::vector<int> chmap;   // reference channel -> internal channel
+  bool split = false;       // split precision: channels [Cp, 2*Cp) hold lo = T(v - float(T(v))) of channels [0, Cp)
+  int stride() const { return split ? 2 * Cp : Cp; }  // channels per pixel in memory
+  int lo_off() const { return split ? Cp : 0; }
 };
 
 struct ConvOp {
@@ -61,6 +64,12 @@ struct ConvOp {
   int level = 0;
   int Cin_p = 0, rowb = 128, nchunk = 1, CoutP = 0, cfg = 0;
   int impl = 0;             // 0 = register-staged kernel (conv_igemm.hip), 1 = LDS-DMA ring (conv_ring.hip)
+  // split precision (RTP_PREC_MIXED / F16X3): the K loop runs the passes [a_hi x W_hi] [a_lo x W_hi] [a_hi x W_lo]
+  bool split_a = false, split_w = false;
+  int ncp = 1;              // chunks of ONE pass (nchunk = ncp * passes)
+  int passes() const { return 1 + (split_a ? 1 : 0) + (split_w ? 1 : 0); }
+  int wrap_at() const { return split_w ? (split_a ? 2 * ncp : ncp) : 0; }
+  int last_phys() const { return split_w ? ncp - 1 : (split_a ? 2 * ncp - 1 : ncp - 1); }
   size_t w_off = 0, b_off = 0, w_bytes = 0;
 };
 
@@ -169,6 +178,8 @@ struct rtp_engine {
   unsigned char* prep_tables = nullptr;
   bool gpu_prep_ok = false;
   bool use_graph = true;
+  int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
+  std::string split_rules;
   unsigned long long* ts_ring = nullptr;  // device: {~(min start), max end} per timed launch (eager mode)
   int ts_next = 0;
   static const int TS_SLOTS = 32768;
@@ -198,6 +209,40 @@ inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline size_t round_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 const int GUARD_PIX = 192;  // pixels of slack before/after each tensor (strip over-read of the last tile)
+
+// ---- split-precision policy ------------------------------------------------------------------
+// Default RTP_PREC_MIXED set, from tools/sim_precision.py (error of the final maps vs an fp32 run, per layer and per
+// rounded operand): the fp16 rounding of weights and activations contributes about equally in every layer, and the
+// final-map error is dominated by the trunk from conv2 on, the last two refinement stages and (cheaply fixed) all 1x1
+// layers; the first refinement stages are attenuated by each later stage's re-injection of conv4_4_CPM.
+const char* kDefaultSplit = "conv2_,conv3_,conv4_,*_stage5_,*_stage6_,@1x1";
+void layer_split(const rtp_engine* e, const ConvOp& c, bool* w, bool* a) {
+  *w = *a = false;
+  if (e->prec != 0) return;
+  if (e->mode == RTP_PREC_F16X3) { *w = *a = true; return; }
+  if (e->mode != RTP_PREC_MIXED) return;
+  const std::string& rules = e->split_rules;
+  size_t pos = 0;
+  while (pos <= rules.size()) {
+    size_t c2 = rules.find(',', pos);
+    std::string tok = rules.substr(pos, c2 == std::string::npos ? std::string::npos : c2 - pos);
+    pos = c2 == std::string::npos ? rules.size() + 1 : c2 + 1;
+    if (tok.empty()) continue;
+    bool tw = true, ta = true;
+    if (tok.size() > 2 && tok[tok.size() - 2] == ':') {
+      const char k = tok.back();
+      tok.resize(tok.size() - 2);
+      if (k == 'w') ta = false;
+      else if (k == 'a') tw = false;
+    }
+    bool hit;
+    if (tok == "@all") hit = true;
+    else if (tok == "@1x1") hit = c.k == 1;
+    else if (tok[0] == '*') hit = c.name.find(tok.substr(1)) != std::string::npos;
+    else hit = c.name.compare(0, tok.size(), tok) == 0;
+    if (hit) { *w = *w || tw; *a = *a || ta; }
+  }
+}
 
 // ---- plan ---------------------------------------------------------------------------------
 int build_plan(rtp_engine* e) {
@@ -392,6 +437,15 @@ int build_plan(rtp_engine* e) {
     c.nchunk = c.Cin_p * e->elem / c.rowb;
   }
 
+  // split precision: which layers, then which tensors must carry a lo block
+  for (auto& c : e->convs) {
+    layer_split(e, c, &c.split_w, &c.split_a);
+    if (c.first) c.split_a = false;  // the image (u8/256 - 0.5) is exact in fp16: its lo part is zero
+    if (c.split_a) e->tensors[c.in_tensor].split = true;
+  }
+  for (size_t pi = e->pools.size(); pi-- > 0;)  // a split pool output needs the lo parts of its input
+    if (e->tensors[e->pools[pi].out_tensor].split) e->tensors[e->pools[pi].in_tensor].split = true;
+
   // steps + pairing + tile configuration
   e->steps.clear();
   e->steps.push_back({0, -1, -1});
@@ -405,7 +459,7 @@ int build_plan(rtp_engine* e) {
       const ConvOp& B = e->convs[cand];
       bool dep = false;
       for (auto& d : A.dsts) if (d.first == B.in_tensor) dep = true;
-      if (!dep && A.k_eff == B.k_eff && A.Cin_p == B.Cin_p && A.level == B.level && A.relu == B.relu && A.rowb == B.rowb &&
+      if (!dep && A.split_a == B.split_a && A.split_w == B.split_w && A.k_eff == B.k_eff && A.Cin_p == B.Cin_p && A.level == B.level && A.relu == B.relu && A.rowb == B.rowb &&
           round_up(A.cout, 64) == round_up(B.cout, 64) && e->tensors[A.in_tensor].Cp == e->tensors[B.in_tensor].Cp)
         b = cand;
     }
@@ -469,11 +523,15 @@ int build_plan(rtp_engine* e) {
     }
   }
 
+  for (auto& c : e->convs) {  // K chunks: one pass = ncp chunks of rowb bytes; split layers run 2-3 passes
+    c.ncp = c.nchunk;
+    c.nchunk = c.ncp * c.passes();
+  }
   // arena layout
   size_t off = 0;
   for (auto& t : e->tensors) {
     const Geom& g = e->geom[t.level];
-    const size_t pix_bytes = (size_t)t.Cp * e->elem;
+    const size_t pix_bytes = (size_t)t.stride() * e->elem;
     off = round_up_sz(off, 256);
     off += GUARD_PIX * pix_bytes;
     off = round_up_sz(off, 256);
@@ -536,7 +594,10 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
           for (int cc = 0; cc < 3; ++cc) {
             const int j = (r * 3 + s) * 3 + cc;
             const int chunk = j / per_chunk, kk = j % per_chunk;
-            pw[((size_t)(0 * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)w[((size_t)(n * 3 + cc) * 3 + r) * 3 + s];
+            const float wv = w[((size_t)(n * 3 + cc) * 3 + r) * 3 + s];
+            const T hi = (T)wv;
+            pw[((size_t)(0 * c.nchunk + chunk) * c.CoutP + n) * per_chunk + kpos(n, kk)] = hi;
+            if (c.split_w) pw[((size_t)(0 * c.nchunk + c.ncp + chunk) * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)(wv - (float)hi);
           }
   } else {
     for (int n = 0; n < c.cout; ++n)
@@ -547,8 +608,18 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
           for (int s = 0; s < c.k; ++s) {
             // register-staged kernel: [tap][chunk]; ring kernel: step order [r][chunk][s]
             const int tap = r * c.k + s;
-            const size_t tile = c.impl == 1 ? ((size_t)(r * c.nchunk + chunk) * c.k + s) : ((size_t)tap * c.nchunk + chunk);
-            pw[(tile * c.CoutP + n) * per_chunk + kpos(n, kk)] = (T)w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
+            const float wv = w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
+            const T hi = (T)wv;
+            const T lo = (T)(wv - (float)hi);
+            // passes of a split layer are further chunks of the K loop: [a_hi x W_hi] [a_lo x W_hi] [a_hi x W_lo]
+            int vbase = 0;
+            for (int pass = 0; pass < 3; ++pass) {
+              if ((pass == 1 && !c.split_a) || (pass == 2 && !c.split_w)) continue;
+              const int vchunk = vbase + chunk;
+              vbase += c.ncp;
+              const size_t tile = c.impl == 1 ? ((size_t)(r * c.nchunk + vchunk) * c.k + s) : ((size_t)tap * c.nchunk + vchunk);
+              pw[(tile * c.CoutP + n) * per_chunk + kpos(n, kk)] = pass == 2 ? lo : hi;
+            }
           }
       }
   }
@@ -577,8 +648,9 @@ void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProbl
   for (int d = 0; d < pr->ndst; ++d) {
     const Tensor& t = e->tensors[c.dsts[d].first];
     pr->dst[d].base = cx.arena + t.offset;
-    pr->dst[d].cstride = t.Cp;
+    pr->dst[d].cstride = t.stride();
     pr->dst[d].coff = c.dsts[d].second;
+    pr->dst[d].lo_off = t.lo_off();
   }
   if (c.to_lowres) {
     pr->out_nchw = cx.lowres;
@@ -596,8 +668,10 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
   fill_problem(e, cx, A, &P.prob[0]);
   if (s.b >= 0) fill_problem(e, cx, e->convs[s.b], &P.prob[1]);
   P.H = g.H; P.W = g.W; P.Wp = g.Wp; P.halo = g.halo; P.img_pix = g.img_pix;
-  P.in_cstride = e->tensors[A.in_tensor].Cp;
+  P.in_cstride = e->tensors[A.in_tensor].stride();
   P.nchunk = A.nchunk;
+  P.wrap_at = A.wrap_at();
+  P.last_phys = A.last_phys();
   P.CoutP = A.CoutP;
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
@@ -613,6 +687,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
     P.ring_sb = (sb && sb[0] == '4') ? 4 : 6;
     static const char* sp = getenv("RTP_RING_SPEC");
     P.spec = (sp && sp[0] == '0') ? 0 : 1;  // wave-specialised ring kernels (default); 0 = every wave does both
+    static const char* rv = getenv("RTP_RING_VAR");
+    P.variant = rv ? atoi(rv) : 0;
   }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
@@ -626,7 +702,7 @@ bool is_dominant_class(const rtp_engine* e, const Step& s) {
   if (s.type != 1 || e->dominant_step < 0) return false;
   const ConvOp& a = e->convs[s.a];
   const ConvOp& d = e->convs[e->steps[e->dominant_step].a];
-  return a.k == d.k && a.cin == d.cin && a.cout == d.cout && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
+  return a.k == d.k && a.cin == d.cin && a.cout == d.cout && a.passes() == d.passes() && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
 }
 
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bool cap = false) {
@@ -636,7 +712,7 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bo
   for (auto& s : e->steps) {
     if (s.type == 0) {
       const Tensor& t = e->tensors[0];
-      HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, geom_n(0), t.Cp, cx.stream));
+      HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, geom_n(0), t.stride(), cx.stream));
     } else if (s.type == 1) {
       unsigned long long* ts = nullptr;
       if (e->time_dominant && is_dominant_class(e, s)) {
@@ -649,8 +725,8 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bo
       const PoolOp& p = pools[s.a];
       const Tensor& ti = e->tensors[p.in_tensor];
       const Tensor& to = e->tensors[p.out_tensor];
-      HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.Cp, cx.arena + to.offset, geom_n(to.level), to.Cp,
-                               round_up(p.C, 16 / e->elem), cx.stream));
+      HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.stride(), cx.arena + to.offset, geom_n(to.level), to.stride(),
+                               round_up(p.C, 16 / e->elem), ti.lo_off(), to.lo_off(), cx.stream));
     }
   }
   return RTP_OK;
@@ -1025,7 +1101,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (cfg->num_scales < 1 || cfg->num_scales > 16) return fail(nullptr, RTP_EINVAL, "num_scales %d out of range", cfg->num_scales);
   if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 64) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
   if (cfg->batch_frames < 0 || cfg->batch_frames > 16) return fail(nullptr, RTP_EINVAL, "batch_frames %d out of range", cfg->batch_frames);
-  if (cfg->precision != RTP_PREC_FP16 && cfg->precision != RTP_PREC_FP32) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
+  if (cfg->precision < RTP_PREC_FP16 || cfg->precision > RTP_PREC_F16X3) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
   if (cfg->exec_mode != RTP_EXEC_GRAPH && cfg->exec_mode != RTP_EXEC_EAGER) return fail(nullptr, RTP_EINVAL, "unknown exec_mode %d", cfg->exec_mode);
   if (cfg->disp_w < 1 || cfg->disp_h < 1) return fail(nullptr, RTP_EINVAL, "bad display resolution");
   // CHECK_LE(target_width, NET_RESOLUTION_WIDTH) (rtpose.cpp:363): every scale must fit the net input
@@ -1045,8 +1121,14 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   e->cfg = *cfg;
   if (cfg->proto_path) { e->proto_path = cfg->proto_path; e->cfg.proto_path = e->proto_path.c_str(); }
   if (cfg->weights_path) { e->weights_path = cfg->weights_path; e->cfg.weights_path = e->weights_path.c_str(); }
-  e->prec = cfg->precision;
-  e->elem = cfg->precision == RTP_PREC_FP16 ? 2 : 4;
+  e->mode = cfg->precision;
+  e->prec = cfg->precision == RTP_PREC_FP32 ? 1 : 0;
+  e->elem = e->prec ? 4 : 2;
+  {
+    const char* sr = getenv("RTP_SPLIT_LAYERS");  // experiments: override the split set of RTP_PREC_MIXED
+    e->split_rules = sr ? sr : (cfg->split_layers ? cfg->split_layers : kDefaultSplit);
+    e->cfg.split_layers = nullptr;
+  }
   e->N = cfg->num_scales;
   e->B = cfg->batch_frames < 1 ? 1 : cfg->batch_frames;
   e->NI = e->N * e->B;
@@ -1475,7 +1557,7 @@ int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int sh
   float* dtmp = nullptr;
   HIPCHK(e, hipMalloc((void**)&dtmp, n * sizeof(float)));
   hipError_t s = hipMemcpy(e->dchmap, t.chmap.data(), t.C * sizeof(int), hipMemcpyHostToDevice);
-  if (s == hipSuccess) s = launch_export(e->prec, cx.arena + t.offset, g, t.Cp, e->dchmap, t.C, dtmp, cx.stream);
+  if (s == hipSuccess) s = launch_export(e->prec, cx.arena + t.offset, g, t.stride(), e->dchmap, t.C, t.lo_off(), dtmp, cx.stream);
   if (s == hipSuccess) s = hipStreamSynchronize(cx.stream);
   if (s == hipSuccess) s = hipMemcpy(out, dtmp, n * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(dtmp);
@@ -1651,8 +1733,14 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   if (!cfg || !buf) return RTP_EINVAL;
   rtp_engine* e = new rtp_engine();
   e->cfg = *cfg;
-  e->prec = cfg->precision;
-  e->elem = cfg->precision == RTP_PREC_FP16 ? 2 : 4;
+  if (cfg->precision < RTP_PREC_FP16 || cfg->precision > RTP_PREC_F16X3) { delete e; return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision); }
+  e->mode = cfg->precision;
+  e->prec = cfg->precision == RTP_PREC_FP32 ? 1 : 0;
+  e->elem = e->prec ? 4 : 2;
+  {
+    const char* sr = getenv("RTP_SPLIT_LAYERS");
+    e->split_rules = sr ? sr : (cfg->split_layers ? cfg->split_layers : kDefaultSplit);
+  }
   e->N = cfg->num_scales;
   e->B = cfg->batch_frames < 1 ? 1 : cfg->batch_frames;
   e->NI = e->N * e->B;
@@ -1674,7 +1762,7 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   for (int l = 0; l < e->nlevels; ++l)
     o << "level " << l << " H " << e->geom[l].H << " W " << e->geom[l].W << " halo " << e->geom[l].halo << "\n";
   o << "arena_bytes " << e->arena_bytes << " weights_bytes " << e->weights_bytes << " tensors " << e->tensors.size() << "\n";
-  double gflop = 0;
+  double gflop = 0, mfma_gflop = 0;
   for (auto& s : e->steps) {
     if (s.type == 0) o << "step pack\n";
     else if (s.type == 2) o << "step pool " << e->tensors[e->pools[s.a].in_tensor].name << " -> " << e->tensors[e->pools[s.a].out_tensor].name << "\n";
@@ -1686,11 +1774,17 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
       o << "step conv " << A.name;
       if (s.b >= 0) o << " + " << e->convs[s.b].name;
       o << " k " << A.k << " cin_p " << A.Cin_p << " cout " << A.cout << " coutp " << A.CoutP << " relu " << A.relu << " tile " << ci.BM << "x" << ci.BN
-        << " rowb " << A.rowb << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->NI * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
-      for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; gflop += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9; }
+        << " rowb " << A.rowb << " passes " << A.passes() << (A.split_a ? "a" : "") << (A.split_w ? "w" : "") << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->NI * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
+      for (int idx : {s.a, s.b}) if (idx >= 0) {
+        const ConvOp& c = e->convs[idx];
+        const double gf = 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9;
+        gflop += gf;
+        mfma_gflop += gf * c.passes();
+      }
     }
   }
   o << "conv_gflop " << gflop << "\n";
+  o << "mfma_gflop " << mfma_gflop << "\n";
   delete e;
   const std::string str = o.str();
   if (str.size() + 1 > buflen) return RTP_ERANGE;
@@ -1753,15 +1847,15 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int ca
     auto once = [&]() -> int {
       if (s.type == 0) {
         const Tensor& t = e->tensors[0];
-        HIPCHK(e, launch_pack_input(e->prec, cx.input, cx.arena + t.offset, geom_n(0), t.Cp, cx.stream));
+        HIPCHK(e, launch_pack_input(e->prec, cx.input, cx.arena + t.offset, geom_n(0), t.stride(), cx.stream));
       } else if (s.type == 1) {
         return launch_conv_step(e, cx, s, e->NI);
       } else {
         const PoolOp& p = e->pools[s.a];
         const Tensor& ti = e->tensors[p.in_tensor];
         const Tensor& to = e->tensors[p.out_tensor];
-        HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.Cp, cx.arena + to.offset, geom_n(to.level), to.Cp,
-                                 round_up(p.C, 16 / e->elem), cx.stream));
+        HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.stride(), cx.arena + to.offset, geom_n(to.level), to.stride(),
+                                 round_up(p.C, 16 / e->elem), ti.lo_off(), to.lo_off(), cx.stream));
       }
       return RTP_OK;
     };

@@ -20,8 +20,9 @@ struct Geom {
 #define RTP_MAX_DST 6
 struct ConvDst {
   void* base;   // element pointer of (n=0, padded pixel 0, channel 0)
-  int cstride;  // channels per pixel (Cp) of the destination tensor
+  int cstride;  // channels per pixel of the destination tensor (2*Cp when it carries a lo block)
   int coff;     // first channel this conv writes
+  int lo_off;   // 0, or the channel offset of the tensor's lo block: channel c also gets lo = T(v - float(T(v))) at lo_off + c
 };
 
 struct ConvProblem {
@@ -39,8 +40,12 @@ struct ConvParams {
   ConvProblem prob[2];  // blockIdx.z selects (the L1 / L2 branch pair shares every shape)
   int H, W, Wp, halo;
   long img_pix;
-  int in_cstride;  // channels per pixel of the input tensor
-  int nchunk;      // Cin_p*sizeof(T)/ROWB
+  int in_cstride;  // channels per pixel of the input tensor (2*Cp when it carries a lo block)
+  int nchunk;      // K chunks per filter row.  Plain layer: Cin_p*sizeof(T)/ROWB.  Split-precision layer: the passes
+                   // [a_hi x W_hi][a_lo x W_hi][a_hi x W_lo] are further chunks of the same K loop (weights are
+                   // packed in that order); the ACTIVATION chunk of virtual chunk v is v, or v - wrap_at from wrap_at on
+  int wrap_at;     // 0 = no wrap (the chunks are contiguous in the input tensor)
+  int last_phys;   // physical chunk index of the last virtual chunk (nchunk-1 without a wrap)
   int CoutP;       // Cout rounded up to a multiple of BN
   int tiles_per_img;
   int nimg;    // images (scales) in the batch
@@ -49,6 +54,7 @@ struct ConvParams {
   int xcdmap;  // 1: contiguous logical range per XCD (decode_block), 0: dispatch order
   int ring_sb; // ring depth request (4 or 6) where both are instantiated
   int spec;    // ring kernel: 1 = wave-specialised variant (4 DMA waves + 4 MFMA waves)
+  int variant; // ring kernel experiments (env RTP_RING_VAR; see conv_ring.hip), 0 = production
   // optional {min start, max end} wall_clock64() slot of this launch (bench.py's in-situ kernel
   // timing: what a profiler's kernel trace reports, unlike stream events which also count the time
   // a launch queues behind other frames' kernels)
@@ -84,10 +90,13 @@ inline int conv_ring_swz(int chb, int row) { return chb == 256 ? (row & 15) : ((
 // (channel (r*3+s)*3+c = in[c][y+r-1][x+s-1], zero outside; channels 27..31 zero).
 hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, int Cp, hipStream_t stream);
 // 2x2 stride-2 MAX pooling between two halo'd NHWC tensors (pooling_layer.cpp:140-180).
-hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C,
+// lo_i / lo_o: 0, or the channel offset of the lo block of a split-precision tensor — the pooled element keeps ITS lo
+// part (the maximum of hi + lo, not two independent maxima).
+hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o,
                           hipStream_t stream);
 // halo'd NHWC (T) -> planar fp32 [N][C][H][W] (debug tap; channel map: out c reads in chmap[c]).
-hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, float* out,
+// lo_off != 0: the tensor carries a lo block, the exported value is hi + lo.
+hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, int lo_off, float* out,
                          hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ import numpy as np
 from ._lib import lib, rtp_config, fp, ip
 
 MODEL_COCO_18, MODEL_MPI_15 = 0, 1
-PREC_FP16, PREC_FP32 = 0, 1
+PREC_FP16, PREC_FP32, PREC_MIXED, PREC_F16X3 = 0, 1, 2, 3
 EXEC_GRAPH, EXEC_EAGER = 0, 1
 MAX_PEOPLE = 96
 
@@ -31,7 +31,7 @@ class Config:
             self.set(k, v)
 
     def set(self, k, v):
-        if k in ("proto_path", "weights_path"):
+        if k in ("proto_path", "weights_path", "split_layers"):
             v = None if v is None else str(v).encode()
             self._keep.append(v)
         setattr(self.c, k, v)

@@ -41,6 +41,12 @@ extern "C" {
 
 #define RTP_PREC_FP16 0 /* fp16 storage, MFMA f16 with fp32 accumulate (headline path)      */
 #define RTP_PREC_FP32 1 /* fp32 storage, exact-f32 MFMA (parity path, 1/16 the MFMA rate)   */
+#define RTP_PREC_MIXED 2 /* fp16 MFMA; the layers named by split_layers (default: the set whose fp16 rounding   *
+                          * dominates the final-map error) run SPLIT: activations and weights as hi + lo fp16   *
+                          * pairs, three MFMA passes a_hi*W_hi + a_lo*W_hi + a_hi*W_lo into one fp32            *
+                          * accumulator (~22 significant bits).  Reference arithmetic is fp32 throughout        *
+                          * (base_conv_layer.cpp:257-280); this is the mode that meets +-1e-3 on the maps.       */
+#define RTP_PREC_F16X3 3 /* every layer split: fp32-class accuracy at about 1/3 of the fp16 rate                 */
 
 #define RTP_EXEC_GRAPH 0 /* default: the static launch plan of one batch (conv stack + every frame's  *
                           * post-processing chain + D2H) is captured ONCE per (engine, frames in the  *
@@ -76,6 +82,10 @@ typedef struct rtp_config {
                             * renderFunctions.cu; part_to_show == 0) for rtp_collect_rendered        */
   int exec_mode;           /* RTP_EXEC_*: how a batch's ~45 launches reach the GPU.  Replaces the  *
                             * reference's per-call layer walk (net.cpp:544-556 ForwardFromTo).       */
+  const char* split_layers;/* RTP_PREC_MIXED only; NULL = default set.  Comma-separated rules, each *
+                            * "<pattern>[:w|:a]": pattern = layer-name prefix, "*text" = name        *
+                            * contains text, "@1x1" = every 1x1 layer, "@all"; ":w" splits only the  *
+                            * weights, ":a" only the input activations, none = both.                  */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,

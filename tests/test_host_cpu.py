@@ -365,3 +365,16 @@ def test_prototxt_kernel_h_w_spelling(tmp_path):
         open(b, "w").write(text.replace("kernel_size: 3", bad, 1))
         with pytest.raises(r.RtpError):
             r.prototxt_summary(b)
+
+
+def test_split_precision_plan_and_rule_syntax():
+    """RTP_PREC_MIXED / F16X3: which layers run the three-pass hi/lo split is host logic (no GPU needed)."""
+    import caffe_rtpose_amd as r
+    base = r.plan_summary(r.Config(precision=r.PREC_FP16))
+    assert "passes 3" not in base and "mfma_gflop 484.6" in base
+    allx = r.plan_summary(r.Config(precision=r.PREC_F16X3))
+    assert "passes 1 " not in allx.replace("passes 1 impl reg wgs 3784", "")   # conv1_1: image exact in fp16, weights split only
+    s = r.plan_summary(r.Config(precision=r.PREC_MIXED, split_layers="conv4_4:w,*_stage6_L:a,@1x1"))
+    lines = {ln.split()[2]: ln for ln in s.splitlines() if ln.startswith("step conv")}
+    assert " passes 2w " in lines["conv4_4_CPM"] and " passes 2a " in lines["Mconv2_stage6_L1"]
+    assert " passes 3aw " in lines["Mconv7_stage6_L1"] and " passes 1 " in lines["conv3_1"]

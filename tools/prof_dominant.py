@@ -5,7 +5,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import caffe_rtpose_amd as r  # noqa: E402
-prec = r.PREC_FP32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else r.PREC_FP16
+prec = {"fp32": r.PREC_FP32, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}.get(sys.argv[1] if len(sys.argv) > 1 else "fp16", r.PREC_FP16)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 e = r.Engine(r.Config(precision=prec, frames_in_flight=batch, batch_frames=batch))

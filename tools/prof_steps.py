@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import caffe_rtpose_amd as r  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 N = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1
-prec = r.PREC_FP32 if (len(sys.argv) > 3 and sys.argv[3] == "fp32") else r.PREC_FP16
+prec = {"fp32": r.PREC_FP32, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}.get(sys.argv[3] if len(sys.argv) > 3 else "fp16", r.PREC_FP16)
 cfg = r.Config(precision=prec, num_scales=N, scale_gap=0.15, frames_in_flight=B, batch_frames=B)
 lines = [l for l in r.plan_summary(cfg).splitlines() if l.startswith("step")]
 e = r.Engine(cfg)
