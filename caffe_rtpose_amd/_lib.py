@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtpose_mi355x.so")
+LIB_PATH = os.environ.get("RTP_LIB") or os.path.join(_HERE, "librtpose_mi355x.so")  # RTP_LIB: kernel experiments with an alternative build
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -174,7 +174,9 @@ constexpr int ring_wait_count(int s) {
 // VAR (experiments on the wave-specialised consumer loop, selected by ConvParams::variant; 0 = production):
 //   1 = all ds_reads of the next tap are issued during the FIRST half of the tap's MFMAs (2 per MFMA), so their LDS
 //       latency is covered by the second half instead of being waited for in front of the barrier
-//   ablations (wrong results, timing only): 11 = no ds_reads, 12 = no MFMAs, 13 = no LDS-DMA
+//   2 = s_setprio 3 on the consumer waves; 3 = accumulators in AGPRs (timing only)
+//   ablations (wrong results, timing only): 11 = no ds_reads, 12 = no MFMAs, 13 = no LDS-DMA,
+//   15 = no per-tap barriers (and no counted waits), 16 = 15 + no ds_reads (a bare MFMA stream)
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0>
 __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvParams P) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
@@ -190,6 +192,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;
   if (P.tstamp && tid == 0) atomicMax(&P.tstamp[0], ~(unsigned long long)wall_clock64());  // slot = {~(min start), max end}, both zero-initialised
+  unsigned long long clk0 = 0, wall0 = 0;
+  if (P.clkprobe && tid == 0 && blockIdx.x == 0) { clk0 = clock64(); wall0 = wall_clock64(); }
   const int lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = SPEC && wave_all >= 4;
@@ -305,8 +309,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       auto pstep = [&](auto s_tag, auto first_tag) {
         constexpr int s = decltype(s_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-        wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
-        __builtin_amdgcn_s_barrier();
+        if constexpr (VAR != 15 && VAR != 16) {
+          wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
+          __builtin_amdgcn_s_barrier();
+        }
         asm volatile("" ::: "memory");
         if constexpr (VAR != 13) {
           if constexpr (s == 0) { abuf ^= 1; issue_a(abuf ^ 1); }
@@ -340,6 +346,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     // ---- consumers ----
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(3);
     read_frags(0, 0, 0, fa, fb);
     auto read_one_c = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) {
       const int gi = idx / (TM + TN), q = idx % (TM + TN);
@@ -350,8 +357,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     constexpr int NMMA_C = GPW * TM * TN, NRD_C = GPW * (TM + TN);
     auto cstep = [&](auto s_tag) {
       constexpr int s = decltype(s_tag)::value;
-      wait_vmcnt<63>();  // lgkmcnt(0): this wave's ds_reads of the stage about to be overwritten have returned
-      __builtin_amdgcn_s_barrier();
+      if constexpr (VAR != 15 && VAR != 16) {
+        wait_vmcnt<63>();  // lgkmcnt(0): this wave's ds_reads of the stage about to be overwritten have returned
+        __builtin_amdgcn_s_barrier();
+      }
       asm volatile("" ::: "memory");
       if constexpr (s == 0) abuf ^= 1;
       const int arow = arow_base + s;
@@ -361,7 +370,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < NMMA_C; ++m) {
-        if constexpr (VAR != 12) {
+        if constexpr (VAR == 3) {  // timing only: accumulators forced into AGPRs (asm MFMA: no hazard padding by hipcc)
+          const int gi = m / (TM * TN), r = m % (TM * TN);
+          const half8_t av = __builtin_bit_cast(half8_t, fa[gi][r / TN]);
+          const half8_t bv = __builtin_bit_cast(half8_t, fb[gi][r % TN]);
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[r / TN][r % TN]) : "v"(av), "v"(bv));
+        } else if constexpr (VAR != 12) {
           const int gi = m / (TM * TN), r = m % (TM * TN);
           Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
         }
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
 #pragma unroll
             for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(rd, pa, pb, aswz);
           }
-        } else if constexpr (VAR != 11) {
+        } else if constexpr (VAR != 11 && VAR != 16) {
 #pragma unroll
           for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rd, pa, pb, aswz);
         }
@@ -406,6 +420,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     if (P.tstamp && tid == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       atomicMax(&P.tstamp[1], (unsigned long long)wall_clock64());
+    }
+    if (P.clkprobe && tid == 0 && blockIdx.x == 0) {  // shader-clock cycles vs 100 MHz wall clock over this workgroup's life
+      P.clkprobe[0] = clock64() - clk0;
+      P.clkprobe[1] = wall_clock64() - wall0;
     }
     return;
   }
@@ -513,6 +531,10 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
         case 11: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 11>(P, nprob, N, stream);
         case 12: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 12>(P, nprob, N, stream);
         case 13: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 13>(P, nprob, N, stream);
+        case 2: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 2>(P, nprob, N, stream);
+        case 3: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 3>(P, nprob, N, stream);
+        case 15: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 15>(P, nprob, N, stream);
+        case 16: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 16>(P, nprob, N, stream);
         default: break;
       }
     }
@@ -544,7 +566,13 @@ template <typename T, int KS>
 static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int nprob, int N, hipStream_t stream) {
   if (chb == 256) {
     if (cfg == CFG_128x32) return ring_launch_one<T, 128, 32, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
-    if (cfg == CFG_128x64) return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
+    if (cfg == CFG_128x64) {
+      if constexpr (KS == 7 && std::is_same<T, _Float16>::value) {  // ring-depth experiments (RTP_RING_SB=3/5) on the dominant plan
+        if (P.ring_sb == 3) return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 3>(P, nprob, N, stream);
+        if (P.ring_sb == 5) return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 5>(P, nprob, N, stream);
+      }
+      return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
+    }
     if (cfg == CFG_64x64) {
       if constexpr (KS == 7) {
         if (P.ring_sb != 4) return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 256, 6>(P, nprob, N, stream);

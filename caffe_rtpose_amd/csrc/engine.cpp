@@ -660,6 +660,7 @@ void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProbl
   pr->Cout = c.cout;
 }
 
+unsigned long long* g_clkprobe = nullptr;  // diagnostics (rtp_bench_dominant_conv under RTP_CLKPROBE)
 int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned long long* tstamp = nullptr) {
   const ConvOp& A = e->convs[s.a];
   const Geom& g = e->geom[A.level];
@@ -677,6 +678,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
   P.relu = A.relu ? 1 : 0;
   P.tstamp = tstamp;
+  P.clkprobe = g_clkprobe;
   P.nimg = nimg;
   {
     static const char* rot = getenv("RTP_CONV_ROTATE");
@@ -684,7 +686,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
     static const char* xm = getenv("RTP_CONV_XCDMAP");
     P.xcdmap = (xm && xm[0] == '0') ? 0 : 1;
     static const char* sb = getenv("RTP_RING_SB");
-    P.ring_sb = (sb && sb[0] == '4') ? 4 : 6;
+    P.ring_sb = sb ? atoi(sb) : 6;
     static const char* sp = getenv("RTP_RING_SPEC");
     P.spec = (sp && sp[0] == '0') ? 0 : 1;  // wave-specialised ring kernels (default); 0 = every wave does both
     static const char* rv = getenv("RTP_RING_VAR");
@@ -1891,6 +1893,22 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   for (int i = 0; i < iters; ++i) if ((rc = launch_conv_step(e, cx, s, e->NI))) return rc;
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
   HIPCHK(e, hipEventSynchronize(cx.ev[1]));
+  if (getenv("RTP_CLKPROBE")) {  // diagnostics: effective shader clock while this kernel runs back to back
+    unsigned long long* d = nullptr;
+    HIPCHK(e, hipMalloc((void**)&d, 16));
+    HIPCHK(e, hipMemset(d, 0, 16));
+    g_clkprobe = d;
+    for (int i = 0; i < 20; ++i) if ((rc = launch_conv_step(e, cx, s, e->NI))) return rc;
+    g_clkprobe = nullptr;
+    HIPCHK(e, hipStreamSynchronize(cx.stream));
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(e, hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
+    if (h[1]) fprintf(stderr, "clkprobe: %llu shader cycles in %llu wall ticks (%d kHz) -> %.0f MHz, workgroup 0 alive %.2f us\n", h[0], h[1], khz,
+                      (double)h[0] / (double)h[1] * khz / 1e3, (double)h[1] / khz * 1e3);
+  }
   float ms = 0.f;
   HIPCHK(e, hipEventElapsedTime(&ms, cx.ev[0], cx.ev[1]));
   if (avg_ms) *avg_ms = ms / iters;

@@ -59,6 +59,7 @@ struct ConvParams {
   // timing: what a profiler's kernel trace reports, unlike stream events which also count the time
   // a launch queues behind other frames' kernels)
   unsigned long long* tstamp;
+  unsigned long long* clkprobe;  // diagnostics: {shader clock cycles, wall clock ticks} of workgroup 0 (spec ring kernels)
 };
 
 // which tile configuration a conv launch uses
