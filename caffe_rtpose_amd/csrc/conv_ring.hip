@@ -172,8 +172,10 @@ constexpr int ring_wait_count(int s) {
 // in-order VMEM issue of a wave (~50 cycles per 1 KiB piece, 3-5 pieces per tap) then no longer sits
 // in front of the same wave's MFMAs.  Same LDS image, same wait counts, one barrier per tap for all.
 // VAR (experiments on the wave-specialised consumer loop, selected by ConvParams::variant; 0 = production):
-//   1 = all ds_reads of the next tap are issued during the FIRST half of the tap's MFMAs (2 per MFMA), so their LDS
-//       latency is covered by the second half instead of being waited for in front of the barrier
+//   production: all ds_reads of the next tap are issued during the FIRST half of the tap's MFMAs (2 per MFMA), so their LDS
+//       latency is covered by the second half instead of being waited for in front of the barrier (-4 % on the dominant launch)
+//   4 = the round-1 schedule: one ds_read per MFMA over the whole tap
+//   17 = 16 with all-zero operands (data dependence of the MFMA rate)
 //   2 = s_setprio 3 on the consumer waves; 3 = accumulators in AGPRs (timing only)
 //   ablations (wrong results, timing only): 11 = no ds_reads, 12 = no MFMAs, 13 = no LDS-DMA,
 //   15 = no per-tap barriers (and no counted waits), 16 = 15 + no ds_reads (a bare MFMA stream)
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       auto pstep = [&](auto s_tag, auto first_tag) {
         constexpr int s = decltype(s_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-        if constexpr (VAR != 15 && VAR != 16) {
+        if constexpr (VAR != 15 && VAR != 16 && VAR != 17) {
           wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
           __builtin_amdgcn_s_barrier();
         }
@@ -348,6 +350,15 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     asm volatile("" ::: "memory");
     if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(3);
     read_frags(0, 0, 0, fa, fb);
+    if constexpr (VAR == 17) {
+#pragma unroll
+      for (int gi = 0; gi < GPW; ++gi) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[gi][i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[gi][j] = make_uint4(0, 0, 0, 0);
+      }
+    }
     auto read_one_c = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) {
       const int gi = idx / (TM + TN), q = idx % (TM + TN);
       const int cl = 2 * (kg * GPW + gi) + lhalf;
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     constexpr int NMMA_C = GPW * TM * TN, NRD_C = GPW * (TM + TN);
     auto cstep = [&](auto s_tag) {
       constexpr int s = decltype(s_tag)::value;
-      if constexpr (VAR != 15 && VAR != 16) {
+      if constexpr (VAR != 15 && VAR != 16 && VAR != 17) {
         wait_vmcnt<63>();  // lgkmcnt(0): this wave's ds_reads of the stage about to be overwritten have returned
         __builtin_amdgcn_s_barrier();
       }
@@ -379,13 +390,13 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
           const int gi = m / (TM * TN), r = m % (TM * TN);
           Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
         }
-        if constexpr (VAR == 1) {  // reads front-loaded: 2 per MFMA over the first half of the tap
+        if constexpr (VAR != 4 && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded: 2 per MFMA over the first half of the tap
           constexpr int HALF = NMMA_C / 2 > 0 ? NMMA_C / 2 : 1;
           if (m < HALF) {
 #pragma unroll
             for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(rd, pa, pb, aswz);
           }
-        } else if constexpr (VAR != 11 && VAR != 16) {
+        } else if constexpr (VAR == 4) {
 #pragma unroll
           for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rd, pa, pb, aswz);
         }
@@ -527,7 +538,8 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
     // experiment variants exist for the dominant plan only (fp16, 7x7, tile 128x64, 256-byte chunks)
     if constexpr (std::is_same<T, _Float16>::value && BM == 128 && BN == 64 && KS == 7 && CHB == 256) {
       switch (P.variant) {
-        case 1: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 1>(P, nprob, N, stream);
+        case 4: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 4>(P, nprob, N, stream);
+        case 17: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 17>(P, nprob, N, stream);
         case 11: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 11>(P, nprob, N, stream);
         case 12: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 12>(P, nprob, N, stream);
         case 13: return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 13>(P, nprob, N, stream);

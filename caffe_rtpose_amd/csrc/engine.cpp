@@ -31,7 +31,9 @@
 
 using namespace rtp;
 
-void rtp_internal_cubic_tab15(short tab[32][4]);
+void rtp_internal_cubic_tab2d(short* tab);
+double rtp_internal_warp_inverse_scale(double s);
+bool rtp_internal_area_fast(int sw, int sh, int dw, int dh, int* ix, int* iy);
 int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::vector<int>* si, std::vector<float>* alpha);
 extern "C" double rtp_display_fit_scale(int ow, int oh, int disp_w, int disp_h);
 extern "C" int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h, int num_scales,
@@ -173,7 +175,7 @@ struct rtp_engine {
   double dom_ms_total = 0;
   long dom_launches = 0;
   // device-side pre-processing (row a1)
-  WarpTab warp_tab;
+  const short* warp_tab_dev = nullptr;  // inside prep_tables
   std::vector<AreaScale> area_scales;   // device pointers inside prep_tables
   unsigned char* prep_tables = nullptr;
   bool gpu_prep_ok = false;
@@ -960,9 +962,8 @@ int use_device(rtp_engine* e) {
 
 // INTER_AREA tables of every pyramid level (display resolution -> 16*ceil(net*s/16)) + cubic table
 int build_prep_tables(rtp_engine* e) {
-  rtp_internal_cubic_tab15(e->warp_tab.w);
   e->gpu_prep_ok = false;
-  struct Host { int tw, th, identity; std::vector<int> xs, xsi, ys, ysi; std::vector<float> xa, ya; };
+  struct Host { int tw, th, identity, fx = 0, fy = 0; std::vector<int> xs, xsi, ys, ysi; std::vector<float> xa, ya; };
   std::vector<Host> hs(e->N);
   size_t bytes = 0;
   for (int i = 0; i < e->N; ++i) {
@@ -972,12 +973,16 @@ int build_prep_tables(rtp_engine* e) {
     h.th = (int)(16 * std::ceil(e->cfg.net_h * scale / 16));
     h.identity = (h.tw == e->cfg.disp_w && h.th == e->cfg.disp_h) ? 1 : 0;
     if (h.tw > e->cfg.disp_w || h.th > e->cfg.disp_h) return RTP_OK;  // enlarging level: host path only
-    if (!h.identity) {
+    if (!h.identity && rtp_internal_area_fast(e->cfg.disp_w, e->cfg.disp_h, h.tw, h.th, &h.fx, &h.fy)) {
+      // integer scale on both axes: block sums, no tables
+    } else if (!h.identity) {
+      h.fx = h.fy = 0;
       if (rtp_internal_area_table(e->cfg.disp_w, h.tw, &h.xs, &h.xsi, &h.xa)) return RTP_OK;
       if (rtp_internal_area_table(e->cfg.disp_h, h.th, &h.ys, &h.ysi, &h.ya)) return RTP_OK;
     }
     bytes += 256 * 6 + (h.xs.size() + h.xsi.size() + h.ys.size() + h.ysi.size()) * sizeof(int) + (h.xa.size() + h.ya.size()) * sizeof(float);
   }
+  bytes += 32 * 32 * 16 * sizeof(short) + 256;
   std::vector<unsigned char> blob(bytes + 256, 0);
   if (e->prep_tables) { (void)hipFree(e->prep_tables); e->prep_tables = nullptr; }
   HIPCHK(e, hipMalloc((void**)&e->prep_tables, blob.size()));
@@ -988,12 +993,18 @@ int build_prep_tables(rtp_engine* e) {
     Host& h = hs[i];
     AreaScale& a = e->area_scales[i];
     a.tw = h.tw; a.th = h.th; a.identity = h.identity;
+    a.fast_x = h.identity ? 0 : h.fx; a.fast_y = h.identity ? 0 : h.fy;
     a.xstart = (const int*)(e->prep_tables + put(h.xs.data(), h.xs.size() * sizeof(int)));
     a.xsi = (const int*)(e->prep_tables + put(h.xsi.data(), h.xsi.size() * sizeof(int)));
     a.xalpha = (const float*)(e->prep_tables + put(h.xa.data(), h.xa.size() * sizeof(float)));
     a.ystart = (const int*)(e->prep_tables + put(h.ys.data(), h.ys.size() * sizeof(int)));
     a.ysi = (const int*)(e->prep_tables + put(h.ysi.data(), h.ysi.size() * sizeof(int)));
     a.yalpha = (const float*)(e->prep_tables + put(h.ya.data(), h.ya.size() * sizeof(float)));
+  }
+  {
+    std::vector<short> t2(32 * 32 * 16);
+    rtp_internal_cubic_tab2d(t2.data());
+    e->warp_tab_dev = (const short*)(e->prep_tables + put(t2.data(), t2.size() * sizeof(short)));
   }
   HIPCHK(e, hipMemcpy(e->prep_tables, blob.data(), blob.size(), hipMemcpyHostToDevice));
   e->gpu_prep_ok = true;
@@ -1019,7 +1030,7 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
   memcpy(sl.frame_host, bgr, fbytes);
   float* dst = cx.input + (size_t)sj * e->N * 3 * e->cfg.net_h * e->cfg.net_w;
   HIPCHK(e, hipMemcpyAsync(sl.frame_dev, sl.frame_host, fbytes, hipMemcpyHostToDevice, cx.stream));
-  HIPCHK(e, launch_warp(sl.frame_dev, w, h, 1.0 / s, e->warp_tab, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
+  HIPCHK(e, launch_warp(sl.frame_dev, w, h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
   HIPCHK(e, launch_area_pad(sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.stream));
   return RTP_OK;
 }

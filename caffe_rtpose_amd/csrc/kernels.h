@@ -103,13 +103,14 @@ hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* ch
 // ---------------------------------------------------------------------------------------
 // Pre-processing on the device (row a1): see preproc.hip
 // ---------------------------------------------------------------------------------------
-struct WarpTab { short w[32][4]; };  // 15-bit fixed-point cubic weights per 1/32-pixel phase
+// warp: BicubicTab_i of OpenCV's initInterTab2D, [fy][fx][k1*4+k2] 15-bit fixed-point weights (device pointer, 32 KiB)
 struct AreaScale {                    // cv::resize(INTER_AREA) tables of one pyramid level (device pointers)
   int tw, th, identity;
+  int fast_x, fast_y;                 // > 0: integer scale on both axes (resizeAreaFast_): block sums instead of the tables
   const int* xstart; const int* xsi; const float* xalpha;   // entries of dst column x: [xstart[x], xstart[x+1])
   const int* ystart; const int* ysi; const float* yalpha;
 };
-hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const WarpTab& tab, unsigned char* dst, int dw, int dh,
+hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
                        hipStream_t stream);
 hipError_t launch_area_pad(const unsigned char* disp, int dw, int dh, const AreaScale* scales, int nscales, float* out, int net_w, int net_h,
                            hipStream_t stream);

@@ -1,8 +1,8 @@
 // preproc.hip — row a1 on the GPU: from the decoded u8 BGR frame to the net input,
 // bit-identical to the host restatement in preprocess.cpp (which restates OpenCV's warpAffine
 // INTER_CUBIC / resize INTER_AREA as used by rtpose.cpp:322-368):
-//   warp_cubic_kernel : display-fit scale, 1/32-pixel fixed-point coordinates, 15-bit cubic weights,
-//                       BORDER_CONSTANT 0 — pure integer arithmetic.
+//   warp_cubic_kernel : display-fit scale, 1/32-pixel fixed-point coordinates, OpenCV's 2-D table of 15-bit cubic weights,
+//                       one rounding per pixel, BORDER_CONSTANT 0 — pure integer arithmetic.
 //   area_pad_kernel   : per scale, fractional-area resize (float accumulation in the host's order:
 //                       x-sum per source row, then beta-weighted row sum), round-to-nearest-even,
 //                       u8/256 - 0.5, centre zero-pad into the net frame (process_and_pad_image).
@@ -16,7 +16,7 @@
 namespace rtp {
 
 __global__ __launch_bounds__(256) void warp_cubic_kernel(const unsigned char* __restrict__ src, int sw, int sh, double inv,
-                                                         WarpTab tab, unsigned char* __restrict__ dst, int dw, int dh) {
+                                                         const short* __restrict__ tab2d, unsigned char* __restrict__ dst, int dw, int dh) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= dw) return;
@@ -25,30 +25,27 @@ __global__ __launch_bounds__(256) void warp_cubic_kernel(const unsigned char* __
   const int Y0 = (int)__double2ll_rn((inv * y) * AB_SCALE) + round_delta;
   const int Y = Y0 >> (AB_BITS - INTER_BITS);
   const int sy = (Y >> INTER_BITS) - 1, fy = Y & (INTER_TAB - 1);
-  const int X0 = (int)__double2ll_rn((inv * x) * AB_SCALE) + round_delta;
-  const int X = X0 >> (AB_BITS - INTER_BITS);
+  const int X = (round_delta + (int)__double2ll_rn(inv * x * AB_SCALE)) >> (AB_BITS - INTER_BITS);
   const int sx = (X >> INTER_BITS) - 1, fx = X & (INTER_TAB - 1);
-  long acc[3] = {0, 0, 0};
+  const short* w = tab2d + ((size_t)fy * 32 + fx) * 16;   // remapBicubic: 16 fixed-point weights, one rounding per pixel
+  int acc[3] = {0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int yy = sy + r;
-    if (yy < 0 || yy >= sh) continue;
-    int row[3] = {0, 0, 0};
+    if (yy < 0 || yy >= sh) continue;   // BORDER_CONSTANT, value 0
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int xx = sx + q;
       if (xx < 0 || xx >= sw) continue;
       const unsigned char* p = src + ((size_t)yy * sw + xx) * 3;
-      const int w = tab.w[fx][q];
-      row[0] += p[0] * w; row[1] += p[1] * w; row[2] += p[2] * w;
+      const int wv = w[r * 4 + q];
+      acc[0] += p[0] * wv; acc[1] += p[1] * wv; acc[2] += p[2] * wv;
     }
-    const long wy = tab.w[fy][r];
-    acc[0] += (long)row[0] * wy; acc[1] += (long)row[1] * wy; acc[2] += (long)row[2] * wy;
   }
   unsigned char* o = dst + ((size_t)y * dw + x) * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const int v = (int)((acc[c] + (1L << (2 * COEF_BITS - 1))) >> (2 * COEF_BITS));
+    const int v = (acc[c] + (1 << (COEF_BITS - 1))) >> COEF_BITS;
     o[c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
   }
 }
@@ -71,6 +68,20 @@ __global__ __launch_bounds__(256) void area_pad_kernel(const unsigned char* __re
   if (sc.identity) {
     const unsigned char* p = disp + ((size_t)oy * dw + ox) * 3;
     r3[0] = p[0]; r3[1] = p[1]; r3[2] = p[2];
+  } else if (sc.fast_x > 0) {  // resizeAreaFast_: integer scale; 2x2 rounds half up, other areas go through float * (1.f/area)
+    int sum[3] = {0, 0, 0};
+    for (int yy = 0; yy < sc.fast_y; ++yy)
+      for (int xx = 0; xx < sc.fast_x; ++xx) {
+        const unsigned char* p = disp + ((size_t)(oy * sc.fast_y + yy) * dw + ox * sc.fast_x + xx) * 3;
+        sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2];
+      }
+    const float inv_area = 1.f / (float)(sc.fast_x * sc.fast_y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int v = (sc.fast_x == 2 && sc.fast_y == 2) ? ((sum[c] + 2) >> 2) : (int)rintf((float)sum[c] * inv_area);
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      r3[c] = (float)v;
+    }
   } else {
     const int xs = sc.xstart[ox], xe = sc.xstart[ox + 1];
     const int ys = sc.ystart[oy], ye = sc.ystart[oy + 1];
@@ -97,10 +108,10 @@ __global__ __launch_bounds__(256) void area_pad_kernel(const unsigned char* __re
   for (int c = 0; c < 3; ++c) o[c * plane] = r3[c] / 256.0f - 0.5f;
 }
 
-hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const WarpTab& tab, unsigned char* dst, int dw, int dh,
+hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
                        hipStream_t stream) {
   dim3 grid((dw + 255) / 256, dh);
-  hipLaunchKernelGGL(warp_cubic_kernel, grid, dim3(256), 0, stream, src, sw, sh, inv, tab, dst, dw, dh);
+  hipLaunchKernelGGL(warp_cubic_kernel, grid, dim3(256), 0, stream, src, sw, sh, inv, tab2d, dst, dw, dh);
   return hipGetLastError();
 }
 

@@ -4,11 +4,12 @@
 //   per scale: cv::resize(INTER_AREA) to 16*ceil(net*s/16) -> process_and_pad_image(normalize=1).
 // OpenCV is a third-party dependency of the reference that is absent here (and whose version the
 // reference does not pin: Makefile:197-202): the two OpenCV primitives below restate OpenCV's
-// published algorithms (imgproc/imgwarp.cpp warpAffine + remap 8u cubic: 1/32-pixel fixed-point
-// coordinates, 15-bit fixed-point weights with A = -0.75; imgproc/resize.cpp computeResizeAreaTab +
-// resizeArea_: fractional-area weights, float accumulation, round-to-nearest-even).
-// PARITY UNPINNED: no test in the reference covers them; the engine's parity boundary is the float
-// NCHW tensor AFTER this stage.
+// published algorithms (imgproc/imgwarp.cpp warpAffine + remapBicubic 8u: 1/32-pixel fixed-point
+// coordinates, the 2-D 15-bit fixed-point weight table of initInterTab2D with A = -0.75, ONE rounding
+// per pixel; resize: scale = 1/(dsize/ssize), resizeAreaFast_ for integer scales, else
+// computeResizeAreaTab + resizeArea_: fractional-area weights, float accumulation, round half to even).
+// Third-party arithmetic: pinned only by tests/_cvref.py, an independent numpy restatement of the same
+// published algorithm (tests/test_preprocess_cli.py, tests/test_gpu_parity.py), not by OpenCV itself.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -19,6 +20,8 @@
 #include <vector>
 
 #include "../../include/rtpose_mi355x.h"
+
+bool rtp_internal_area_fast(int sw, int sh, int dw, int dh, int* ix, int* iy);
 
 namespace {
 
@@ -64,10 +67,32 @@ void resize_linear_u8(const unsigned char* src, int sw, int sh, unsigned char* d
   }
 }
 
+}  // namespace
+// is_area_fast of cv::resize: both scale factors are integers (compared with DBL_EPSILON)
+bool rtp_internal_area_fast(int sw, int sh, int dw, int dh, int* ix, int* iy) {
+  const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
+  *ix = (int)std::lrint(sx);
+  *iy = (int)std::lrint(sy);
+  return std::fabs(sx - *ix) < 2.220446049250313e-16 && std::fabs(sy - *iy) < 2.220446049250313e-16 && *ix >= 1 && *iy >= 1 && !(*ix == 1 && *iy == 1);
+}
+namespace {
 void resize_area_u8(const unsigned char* src, int sw, int sh, unsigned char* dst, int dw, int dh) {
   if (dw == sw && dh == sh) { memcpy(dst, src, (size_t)sw * sh * 3); return; }
   if (dw > sw || dh > sh) { resize_linear_u8(src, sw, sh, dst, dw, dh); return; }
-  const double sx = (double)sw / dw, sy = (double)sh / dh;
+  const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);  // resize(): scale_x = 1./inv_scale_x
+  int ix = 0, iy = 0;
+  if (rtp_internal_area_fast(sw, sh, dw, dh, &ix, &iy)) {  // resizeAreaFast_: integer scale on both axes
+    const float inv_area = 1.f / (float)(ix * iy);
+    for (int dy = 0; dy < dh; ++dy)
+      for (int dx = 0; dx < dw; ++dx)
+        for (int c = 0; c < 3; ++c) {
+          int sum = 0;
+          for (int yy = 0; yy < iy; ++yy)
+            for (int xx = 0; xx < ix; ++xx) sum += src[((size_t)(dy * iy + yy) * sw + dx * ix + xx) * 3 + c];
+          dst[((size_t)dy * dw + dx) * 3 + c] = (ix == 2 && iy == 2) ? (unsigned char)((sum + 2) >> 2) : sat_u8(cv_round((float)sum * inv_area));
+        }
+    return;
+  }
   std::vector<AreaTab> xt, yt;
   area_tab(sw, dw, sx, xt);
   area_tab(sh, dh, sy, yt);
@@ -96,46 +121,72 @@ void cubic_coeffs(float x, float* c) {
   c[3] = 1.f - c[0] - c[1] - c[2];
 }
 
-// 1-D cubic tables in 15-bit fixed point (initInterTab2D: weights sum to 1 << 15, the remainder goes to the largest)
-void cubic_tab15(short tab[32][4]) {
-  const int COEF_BITS = 15;
-  for (int i = 0; i < 32; ++i) {
-    float c[4];
-    cubic_coeffs((float)i / 32, c);
-    int isum = 0, kmax = 0;
-    for (int k = 0; k < 4; ++k) { tab[i][k] = (short)cv_round(c[k] * (1 << COEF_BITS)); isum += tab[i][k]; if (c[k] > c[kmax]) kmax = k; }
-    tab[i][kmax] = (short)(tab[i][kmax] + ((1 << COEF_BITS) - isum));
-  }
+// BicubicTab_i of initInterTab2D(INTER_CUBIC, fixpt): for every (fy, fx) phase pair the 16 weights
+// saturate_cast<short>(wy[k1] * wx[k2] * 32768) of the FLOAT 1-D weights; when they do not sum to 32768 the difference
+// goes to the largest (sum too small) or the smallest (sum too large) of the four entries k1, k2 in {2, 3}.
+void cubic_tab2d(short* tab /* [32][32][16] */) {
+  float t1[32][4];
+  const float scale = 1.f / 32;
+  for (int i = 0; i < 32; ++i) cubic_coeffs(i * scale, t1[i]);
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      short* it = tab + ((size_t)i * 32 + j) * 16;
+      int isum = 0;
+      for (int k1 = 0; k1 < 4; ++k1) {
+        const float vy = t1[i][k1];
+        for (int k2 = 0; k2 < 4; ++k2) {
+          const float v = vy * t1[j][k2];
+          const int q = cv_round(v * 32768.f);
+          it[k1 * 4 + k2] = (short)(q < -32768 ? -32768 : (q > 32767 ? 32767 : q));
+          isum += it[k1 * 4 + k2];
+        }
+      }
+      if (isum != 32768) {
+        const int diff = isum - 32768;
+        int Mk = 2 * 4 + 2, mk = 2 * 4 + 2;
+        for (int k1 = 2; k1 < 4; ++k1)
+          for (int k2 = 2; k2 < 4; ++k2) {
+            if (it[k1 * 4 + k2] < it[mk]) mk = k1 * 4 + k2;
+            else if (it[k1 * 4 + k2] > it[Mk]) Mk = k1 * 4 + k2;
+          }
+        if (diff < 0) it[Mk] = (short)(it[Mk] - diff);
+        else it[mk] = (short)(it[mk] - diff);
+      }
+    }
+}
+
+// warpAffine inverts M = diag(s, s) itself: D = 1/(M0*M4 - M1*M3); A11 = M4*D
+double warp_inverse_scale(double s) {
+  double D = s * s;
+  D = D != 0 ? 1.0 / D : 0;
+  return s * D;
 }
 
 void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale, unsigned char* dst, int dw, int dh) {
   const int INTER_BITS = 5, INTER_TAB = 1 << INTER_BITS, AB_BITS = 10, AB_SCALE = 1 << AB_BITS, COEF_BITS = 15;
-  short tab[32][4];
-  cubic_tab15(tab);
-  const double inv = 1.0 / scale;  // warpAffine inverts M unless WARP_INVERSE_MAP
+  static const std::vector<short> tab = [] { std::vector<short> t(32 * 32 * 16); cubic_tab2d(t.data()); return t; }();
+  const double inv = warp_inverse_scale(scale);
   const int round_delta = AB_SCALE / INTER_TAB / 2;
   for (int y = 0; y < dh; ++y) {
     const int Y0 = (int)std::lrint((inv * y) * AB_SCALE) + round_delta;
     const int Y = Y0 >> (AB_BITS - INTER_BITS);
     const int sy = (Y >> INTER_BITS) - 1, fy = Y & (INTER_TAB - 1);
     for (int x = 0; x < dw; ++x) {
-      const int X0 = (int)std::lrint((inv * x) * AB_SCALE) + round_delta;
-      const int X = X0 >> (AB_BITS - INTER_BITS);
+      const int X = (round_delta + (int)std::lrint(inv * x * AB_SCALE)) >> (AB_BITS - INTER_BITS);  // (X0 + adelta[x]) >> 5, X0 = 16
       const int sx = (X >> INTER_BITS) - 1, fx = X & (INTER_TAB - 1);
+      const short* w = tab.data() + ((size_t)fy * 32 + fx) * 16;
       for (int c = 0; c < 3; ++c) {
-        long acc = 0;
+        int acc = 0;
         for (int r = 0; r < 4; ++r) {
           const int yy = sy + r;
           if (yy < 0 || yy >= sh) continue;  // BORDER_CONSTANT 0
-          int row = 0;
           for (int q = 0; q < 4; ++q) {
             const int xx = sx + q;
             if (xx < 0 || xx >= sw) continue;
-            row += src[((size_t)yy * sw + xx) * 3 + c] * tab[fx][q];
+            acc += src[((size_t)yy * sw + xx) * 3 + c] * w[r * 4 + q];
           }
-          acc += (long)row * tab[fy][r];
         }
-        dst[((size_t)y * dw + x) * 3 + c] = sat_u8((int)((acc + (1L << (2 * COEF_BITS - 1))) >> (2 * COEF_BITS)));
+        dst[((size_t)y * dw + x) * 3 + c] = sat_u8((acc + (1 << (COEF_BITS - 1))) >> COEF_BITS);  // FixedPtCast<int, uchar, 15>
       }
     }
   }
@@ -144,11 +195,12 @@ void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale,
 }  // namespace
 
 // shared with the device path (engine.cpp uploads exactly these tables)
-void rtp_internal_cubic_tab15(short tab[32][4]) { cubic_tab15(tab); }
+void rtp_internal_cubic_tab2d(short* tab) { cubic_tab2d(tab); }
+double rtp_internal_warp_inverse_scale(double s) { return warp_inverse_scale(s); }
 int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::vector<int>* si, std::vector<float>* alpha) {
   if (dsize > ssize) return -1;  // enlarging: the host path falls back to linear interpolation
   std::vector<AreaTab> tab;
-  area_tab(ssize, dsize, (double)ssize / dsize, tab);
+  area_tab(ssize, dsize, 1.0 / ((double)dsize / ssize), tab);
   start->assign(dsize + 1, 0);
   si->clear();
   alpha->clear();

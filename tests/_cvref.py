@@ -43,7 +43,7 @@ def bicubic_tab_i():
     for i in range(32):
         for j in range(32):
             v = (t1[i][:, None] * t1[j][None, :]).astype(np.float32)            # float product vy*vx
-            it = np.rint((v * np.float32(32768)).astype(np.float32)).astype(np.int64)   # saturate_cast<short>: cvRound
+            it = np.clip(np.rint((v * np.float32(32768)).astype(np.float32)), -32768, 32767).astype(np.int64)   # saturate_cast<short>(cvRound)
             diff = int(it.sum()) - 32768
             if diff:
                 Mk = mk = (2, 2)

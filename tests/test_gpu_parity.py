@@ -591,3 +591,28 @@ def test_graph_replay_equals_eager_launches(B):
     assert eg.last_stage_ms()["total"] > 0
     eg.close()
     ee.close()
+
+
+# ------------------------------------------------------------------------------------------
+# row a1 / f1 on the device against the independent OpenCV restatement (tests/_cvref.py) + the reference's own
+# process_and_pad_image semantics (oracle, pinned on oracle/_ref): not product vs product
+# ------------------------------------------------------------------------------------------
+def _a1_geoms():
+    from test_preprocess_cli import GEOMS
+    return GEOMS
+
+
+@pytest.mark.parametrize("geom", _a1_geoms())
+def test_device_preprocess_equals_independent_opencv_restatement(geom):
+    import caffe_rtpose_amd as r
+    import _cvref
+    from test_preprocess_cli import _frame
+    fw, fh, dw, dh, W, H, N, start, gap = geom
+    e = _engine(net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, disp_w=dw, disp_h=dh, frames_in_flight=1)
+    img = _frame(fw, fh, seed=fw + fh)
+    want_x, want_disp, want_fs = _cvref.producer_frame(img, dw, dh, W, H, N, start, gap, orc.process_and_pad_image)
+    x, disp, fs = e.debug_preprocess(img)
+    assert fs == want_fs
+    assert np.array_equal(disp, want_disp)
+    assert np.array_equal(x, want_x)
+    e.close()

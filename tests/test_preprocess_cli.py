@@ -299,3 +299,55 @@ def test_cli_frame_drops_and_no_frame_drops(tmp_path):
     m = re.search(rb"frames produced (\d+), written (\d+), dropped (\d+)", p.stderr)
     assert tuple(int(x) for x in m.groups()) == (40, 40, 0)
     assert sorted(os.listdir(out2)) == [f"frame{i:06d}.json" for i in range(40)]
+
+
+# ------------------------------------------------------------------------------------------
+# row a1 against something that is NOT the product: tests/_cvref.py, an independent numpy restatement of OpenCV's
+# published warpAffine(INTER_CUBIC) / resize(INTER_AREA) (2-D fixed-point table, one rounding per pixel, area fast path)
+# ------------------------------------------------------------------------------------------
+GEOMS = [  # (frame w, h, display w, h, net w, h, scales, start, gap)
+    (640, 480, 1280, 720, 656, 368, 1, 1.0, 0.3),      # BASELINE config 1: 640x480 jpg, enlarging display warp (s = 1.5)
+    (1280, 720, 1280, 720, 656, 368, 3, 1.0, 0.15),    # configs 2-4: identity warp, 3 pyramid levels
+    (1920, 1080, 1280, 720, 656, 368, 2, 1.0, 0.25),   # shrinking warp (s = 2/3)
+    (500, 375, 640, 360, 320, 176, 1, 1.0, 0.3),       # portrait-ish frame: right part of the display stays black
+    (333, 500, 1312, 736, 656, 368, 1, 1.0, 0.3),      # display = 2x the net: resizeAreaFast_ 2x2
+    (320, 240, 960, 528, 320, 176, 1, 1.0, 0.3),       # display = 3x the net: resizeAreaFast_ general
+]
+
+
+def _frame(w, h, seed):
+    rs = np.random.RandomState(seed)
+    base = rs.randint(0, 256, size=(h // 8 + 2, w // 8 + 2, 3)).astype(np.float32)
+    img = np.kron(base, np.ones((8, 8, 1), np.float32))[:h, :w]                   # blocks: edges + flat areas
+    img = img * 0.7 + rs.randint(0, 77, size=(h, w, 3))                            # + noise: every rounding case occurs
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_host_preprocess_equals_independent_opencv_restatement(geom):
+    import caffe_rtpose_amd as r
+    import _cvref
+    import _oracle as orc
+    fw, fh, dw, dh, W, H, N, start, gap = geom
+    img = _frame(fw, fh, seed=fw + fh)
+    x, disp, fs = r.preprocess_frame(img, dw, dh, W, H, N, start, gap)
+    want_x, want_disp, want_fs = _cvref.producer_frame(img, dw, dh, W, H, N, start, gap, orc.process_and_pad_image)
+    assert fs == want_fs
+    assert np.array_equal(disp, want_disp), f"display warp differs in {(disp != want_disp).mean():.2%} of the bytes"
+    assert np.array_equal(x, want_x)
+
+
+def test_cvref_table_and_primitives_self_checks():
+    """Properties of the restatement itself: every 2-D weight set sums to 1 << 15 (at phase (0,0) the weight 1.0 saturates
+    to 32767 and initInterTab2D's correction puts the missing 1 on entry [2][2]: still the identity on u8 data); an
+    integer down-scale by 2 is the rounded-half-up block mean; identity resize is a copy."""
+    import _cvref
+    tab = _cvref.bicubic_tab_i()
+    assert tab.shape == (32, 32, 4, 4) and np.all(tab.sum(axis=(2, 3)) == 32768)
+    assert tab[0, 0, 1, 1] == 32767 and tab[0, 0, 2, 2] == 1 and np.count_nonzero(tab[0, 0]) == 2
+    img = _frame(64, 48, 5)
+    assert np.array_equal(_cvref.warp_affine_scale_cubic(img, 1.0, 64, 48), img)
+    half = _cvref.resize_area(img, 32, 24)
+    blk = img.astype(np.int64).reshape(24, 2, 32, 2, 3).sum(axis=(1, 3))
+    assert np.array_equal(half, ((blk + 2) >> 2).astype(np.uint8))
+    assert np.array_equal(_cvref.resize_area(img, 64, 48), img)
