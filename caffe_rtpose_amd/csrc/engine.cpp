@@ -128,7 +128,8 @@ struct Ctx {
   // per (timed?, frames in the batch) and replayed; gev = {before, after} the replay on `stream`
   hipGraphExec_t gexec[2][17] = {};
   hipEvent_t gev[2] = {nullptr, nullptr};
-  bool graph_run = false;                 // the batch in flight was a graph replay (collect waits on gev[1])
+  bool graph_run = false;                 // the batch in flight was ONE graph replay incl. post-processing (collect waits on gev[1])
+  bool graph_conv = false;                // the conv stack was a replay, the post-processing chains were launched eagerly
   unsigned long long* ts_dev = nullptr;   // in-kernel {~start, end} stamps of the dominant-class launches of one replay
   unsigned long long* ts_host = nullptr;  // pinned copy, written by the graph after the conv stack
   int ts_n = 0;
@@ -180,6 +181,7 @@ struct rtp_engine {
   unsigned char* prep_tables = nullptr;
   bool gpu_prep_ok = false;
   bool use_graph = true;
+  bool graph_post = false;  // RTP_GRAPH_POST=1: also capture the per-frame post-processing chains + D2H into the batch graph
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
   std::string split_rules;
   unsigned long long* ts_ring = nullptr;  // device: {~(min start), max end} per timed launch (eager mode)
@@ -791,14 +793,17 @@ int run_post_fused(rtp_engine* e, Ctx& cx, int sj, hipEvent_t ev_nms) {
 
 // one batch on one context: conv stack over nframes*num_scales images, then per frame (on the
 // frame slot's stream) resize -> nms -> connect -> D2H of the joints
-int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize, bool cap) {
+int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize, bool cap, int part = 3) {
   int rc;
-  HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
-  if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N, cap))) return rc;
-  if (cap && cx.ts_n > 0) {  // hand the stamps of this replay to the host and re-arm the slots
-    HIPCHK(e, hipMemcpyAsync(cx.ts_host, cx.ts_dev, (size_t)2 * cx.ts_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, cx.stream));
-    HIPCHK(e, hipMemsetAsync(cx.ts_dev, 0, (size_t)2 * cx.ts_n * sizeof(unsigned long long), cx.stream));
+  if (part & 1) {
+    HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
+    if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N, cap))) return rc;
+    if (cap && cx.ts_n > 0) {  // hand the stamps of this replay to the host and re-arm the slots
+      HIPCHK(e, hipMemcpyAsync(cx.ts_host, cx.ts_dev, (size_t)2 * cx.ts_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, cx.stream));
+      HIPCHK(e, hipMemsetAsync(cx.ts_dev, 0, (size_t)2 * cx.ts_n * sizeof(unsigned long long), cx.stream));
+    }
   }
+  if (!(part & 2)) return RTP_OK;
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
   const size_t jbytes = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3 * sizeof(float);
   for (int j = 0; j < nframes; ++j) {
@@ -847,7 +852,7 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
 int capture_batch(rtp_engine* e, Ctx& cx, int nframes, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   HIPCHK(e, hipStreamBeginCapture(cx.stream, hipStreamCaptureModeThreadLocal));
-  const int rc = launch_batch_body(e, cx, nframes, cx.input, false, true);
+  const int rc = launch_batch_body(e, cx, nframes, cx.input, false, true, e->graph_post ? 3 : 1);
   const hipError_t s = hipStreamEndCapture(cx.stream, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (s != hipSuccess || !g) return fail(e, RTP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(s));
@@ -863,6 +868,7 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
   static const char* unf = getenv("RTP_POST_UNFUSED");
   const bool graph = e->use_graph && !materialize && input_dev == cx.input && !e->cfg.render && !diag && !unf && nframes <= 16;
   cx.graph_run = graph;
+  cx.graph_conv = false;
   if (!graph) {
     if ((rc = launch_batch_body(e, cx, nframes, input_dev, materialize, false))) return rc;
     cx.launched = true;
@@ -877,6 +883,11 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
   if (!cx.gexec[t][nframes] && (rc = capture_batch(e, cx, nframes, &cx.gexec[t][nframes]))) return rc;
   HIPCHK(e, hipEventRecord(cx.gev[0], cx.stream));
   HIPCHK(e, hipGraphLaunch(cx.gexec[t][nframes], cx.stream));
+  if (!e->graph_post) {  // the conv stack is one replay; every frame's short post-processing chain is launched eagerly on its slot's stream
+    if ((rc = launch_batch_body(e, cx, nframes, cx.input, false, false, 2))) return rc;
+    cx.graph_run = false;            // collect waits for the frame's own event, not for the whole batch
+    cx.graph_conv = true;
+  }
   HIPCHK(e, hipEventRecord(cx.gev[1], cx.stream));
   cx.ts_pending = t != 0;
   cx.launched = true;
@@ -1152,6 +1163,8 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     e->use_graph = cfg->exec_mode == RTP_EXEC_GRAPH;
     if (eg && !strcmp(eg, "eager")) e->use_graph = false;
     if (eg && !strcmp(eg, "graph")) e->use_graph = true;
+    const char* gp = getenv("RTP_GRAPH_POST");
+    e->graph_post = gp && gp[0] == '1';
   }
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
 
@@ -1363,7 +1376,8 @@ static void stage_ms(rtp_engine* e, Ctx& cx, Slot& sl) {
     e->last_ms[4] = ms;
     return;
   }
-  hipEvent_t a[5] = {cx.ev[0], sl.ev[0], sl.ev[1], sl.ev[2], cx.ev[0]};
+  hipEvent_t start = cx.graph_conv ? cx.gev[0] : cx.ev[0];  // the conv stack's own start event lives inside the replay
+  hipEvent_t a[5] = {start, sl.ev[0], sl.ev[1], sl.ev[2], start};
   hipEvent_t b[5] = {cx.ev[1], sl.ev[1], sl.ev[2], sl.ev[3], sl.ev[4]};
   for (int i = 0; i < 5; ++i) {
     float ms = 0.f;
@@ -1390,7 +1404,7 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   Slot& sl = cx.slot[sj];
   if (!cx.launched && (rc = launch_open(e))) return rc;  // the oldest frame sits in a partial batch
   HIPCHK(e, hipEventSynchronize(cx.graph_run ? cx.gev[1] : sl.ev[4]));
-  if (cx.graph_run && cx.ts_pending) {  // dominant-kernel stamps of this replay (rtp_kernel_timing)
+  if ((cx.graph_run || cx.graph_conv) && cx.ts_pending) {  // dominant-kernel stamps of this replay (rtp_kernel_timing)
     int khz = 100000;
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
     for (int i = 0; i < cx.ts_n; ++i) {

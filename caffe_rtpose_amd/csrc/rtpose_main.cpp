@@ -151,6 +151,7 @@ struct Global {
   std::atomic<bool> quit_threads{false};
   std::atomic<int> produced{0}, finished{0}, dropped{0};
   std::vector<int> per_worker;  // frames each worker submitted (dynamic pull from the one shared queue)
+  std::atomic<int> workers_ready{0};  // workers start pulling once EVERY engine is up (engine creation takes seconds, short inputs milliseconds)
   std::atomic<bool> producer_done{false};
   int num_parts = 18;
   std::vector<std::string> image_list;
@@ -192,6 +193,7 @@ void producer() {
     if (rtp_load_image(path.c_str(), d.bgr.data(), d.bgr.size(), &d.w, &d.h) != RTP_OK) { d.err = rtp_codec_last_error(); d.w = 0; }
     return d;
   };
+  while (G.workers_ready.load() < F.num_gpu && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));  // no frame ages while the engines start
   for (int fi = F.start_frame; fi < nframes && !G.quit_threads; ++fi) {
     // back-pressure (rtpose.cpp:311, 424-429)
     while (G.input_queue.size() > 10 && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(10));
@@ -266,6 +268,8 @@ void worker(int widx, int device, int* status) {
   rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
   G.num_parts = num_parts;
   fprintf(stderr, "GPU %d is ready\n", device);
+  G.workers_ready++;
+  while (G.workers_ready.load() < F.num_gpu && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   std::deque<Frame> inflight;
   std::vector<float> joints((size_t)RTP_MAX_PEOPLE * num_parts * 3);
   auto collect_one = [&]() {

@@ -351,3 +351,64 @@ def test_cvref_table_and_primitives_self_checks():
     blk = img.astype(np.int64).reshape(24, 2, 32, 2, 3).sum(axis=(1, 3))
     assert np.array_equal(half, ((blk + 2) >> 2).astype(np.uint8))
     assert np.array_equal(_cvref.resize_area(img, 64, 48), img)
+
+
+@pytest.mark.gpu
+def test_cpp_net_api_mirror_runs_on_the_gpu(tmp_path):
+    """INTEGRATION.md path A executed, not just linked: a C++ program written against csrc/host_api.h (the Net API names
+    rtpose.cpp uses: Net, CopyTrainedLayersFrom, blobs()[0]->Reshape, layer_by_name("nms"/"resize"), ForwardFrom(0),
+    blob_by_name("resized_map"/"joints")) returns the blobs the ctypes path returns for the same frame."""
+    import caffe_rtpose_amd as r
+    W, H, N = 160, 96, 2
+    proto, model = tmp_path / "net.prototxt", tmp_path / "net.caffemodel"
+    r.write_builtin_prototxt(r.MODEL_COCO_18, proto)
+    r.write_synthetic_caffemodel(r.MODEL_COCO_18, 7, model)
+    x = r.preprocess_frame(r.synth_frame(320, 240, 3, seed=8), 320, 240, W, H, N, 1.0, 0.25)[0]
+    x.tofile(tmp_path / "in.f32")
+    src = tmp_path / "use.cpp"
+    src.write_text('''
+#include <cstdio>
+#include <vector>
+#include "caffe_rtpose_amd/csrc/host_api.h"
+int main(int argc, char** argv) {
+  rtpose::Net net(argv[1], rtpose::TEST, 0);
+  net.CopyTrainedLayersFrom(argv[2]);
+  net.set_display_resolution(320, 240);
+  net.blobs()[0]->Reshape({%d, 3, %d, %d});
+  auto resize = net.layer_by_name<rtpose::ImResizeLayer>("resize");
+  resize->SetStartScale(1.f); resize->SetScaleGap(0.25f);
+  net.Reshape();
+  auto nms = net.layer_by_name<rtpose::NmsLayer>("nms");
+  nms->SetThreshold(0.05f);
+  FILE* f = fopen(argv[3], "rb");
+  auto in = net.blobs()[0];
+  if (!f || fread(in->mutable_cpu_data(), sizeof(float), in->data_.size(), f) != in->data_.size()) return 3;
+  fclose(f);
+  net.ForwardFrom(0);
+  auto res = net.blob_by_name("resized_map");
+  auto jo = net.blob_by_name("joints");
+  FILE* o = fopen(argv[4], "wb");
+  const int hdr[4] = {nms->GetMaxPeaks(), nms->GetNumParts(), (int)res->data_.size(), (int)jo->data_.size()};
+  fwrite(hdr, sizeof(int), 4, o);
+  fwrite(res->cpu_data(), sizeof(float), res->data_.size(), o);
+  fwrite(jo->cpu_data(), sizeof(float), jo->data_.size(), o);
+  fclose(o);
+  return 0;
+}
+''' % (N, H, W))
+    exe = tmp_path / "use"
+    subprocess.check_call(["g++", "-std=c++17", "-I", ROOT, "-o", str(exe), str(src), "-L", os.path.join(ROOT, "caffe_rtpose_amd"),
+                           "-lrtpose_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "caffe_rtpose_amd")])
+    p = subprocess.run([str(exe), str(proto), str(model), str(tmp_path / "in.f32"), str(tmp_path / "out.bin")], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    raw = open(tmp_path / "out.bin", "rb").read()
+    hdr = np.frombuffer(raw[:16], np.int32)
+    assert tuple(hdr[:2]) == (64, 18)
+    res = np.frombuffer(raw[16:16 + 4 * hdr[2]], np.float32).reshape(57, H, W)
+    peaks = np.frombuffer(raw[16 + 4 * hdr[2]:], np.float32).reshape(18, 65, 3)
+    e = r.Engine(r.Config(proto_path=str(proto), weights_path=str(model), net_w=W, net_h=H, num_scales=N, scale_gap=0.25, disp_w=320, disp_h=240,
+                          frames_in_flight=1))
+    d = e.forward_debug(x)
+    assert np.array_equal(res, d["resized"]) and np.array_equal(peaks, d["peaks"])
+    assert peaks[:, 0, 0].sum() > 0
+    e.close()
