@@ -34,7 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 PREC_NOTE = {
-    "mixed": "fp16 MFMA, fp32 accumulate; conv2_*..conv4_*, refinement stages 5-6 and all 1x1 layers run as hi+lo fp16 pairs (a_hi*W_hi + a_lo*W_hi + a_hi*W_lo): "
+    "mixed": "fp16 MFMA, fp32 accumulate; conv2_*..conv4_*, refinement stages 4-6 and all 1x1 layers run as hi+lo fp16 pairs (a_hi*W_hi + a_lo*W_hi + a_hi*W_lo): "
              "final maps within 1e-3 of the fp32 reference (normalised to max 1), tests/test_precision.py",
     "fp16": "fp16 storage and MFMA everywhere, fp32 accumulate: final maps 2.0-2.6e-3 from the fp32 reference, OUTSIDE the +-1e-3 north-star tolerance",
     "f16x3": "every layer as hi+lo fp16 pairs in three MFMA passes: fp32-class accuracy",

@@ -85,6 +85,22 @@ hipError_t launch_conv(int prec, int cfg, int ks, int rowb, const ConvParams& P,
 // tile); weights packed with the matching 16-byte-chunk swizzle (see conv_ring.hip).
 hipError_t launch_conv_ring(int prec, int cfg, int ks, int chb, const ConvParams& P, int nprob, int N,
                             hipStream_t stream);
+// Two chained 1x1 convolutions in one launch (conv_pw2.hip): Y = W2 * act(W1 * X + b1) + b2, fp16 MFMA, Cin = 128 channels,
+// middle layer a multiple of 128 channels, Cout <= 64.  P2 describes the SECOND convolution (destinations, bias, geometry;
+// prob[].w = W2 packed [chunk][part][64][128]); the fields below the first one.
+struct Pw2Params {
+  ConvParams P2;
+  const void* x_in[2];     // input tensor of the first convolution (element pointer of padded pixel 0)
+  int x_cstride, x_lo_off; // channels per pixel; 0 or the offset of the input's lo block (split precision)
+  const void* w1[2];       // W1 packed [chunk][part (hi, lo)][128][128]
+  const float* b1[2];
+  ConvDst mid[2];          // the middle layer's own blob tensor (base may be null)
+  int c1_chunks;           // middle channels / 128
+  int relu1;
+  int split_w1, split_w2, h_lo;  // split precision: lo weights of either layer; lo part of the middle activations
+};
+hipError_t launch_conv_pw2(const Pw2Params& Q, int nprob, int nimg, hipStream_t stream);
+
 inline int conv_ring_swz(int chb, int row) { return chb == 256 ? (row & 15) : ((row >> 1) & 7); }
 
 // NCHW fp32 [N][3][H][W] -> level-0 tensor with 32 channels = 3x3 im2col of the image

@@ -69,16 +69,21 @@ def _plan_lines(**kw):
 def test_plan_coco_flops_and_pairing():
     lines = _plan_lines()
     assert lines[0] == "model 0 parts 18 max_peaks 64 heat_channels 57"
-    assert float(lines[-1].split()[1]) == pytest.approx(484.634, abs=1e-3)
+    gf = {l.split()[0]: float(l.split()[1]) for l in lines if l.startswith(("conv_gflop", "mfma_gflop"))}
+    assert gf["conv_gflop"] == pytest.approx(484.634, abs=1e-3)
+    assert gf["mfma_gflop"] == pytest.approx(484.634, abs=1e-3)  # fp16: one MFMA pass per layer
     convs = [l for l in lines if l.startswith("step conv")]
-    assert len(convs) == 12 + 5 + 35  # 12 VGG/CPM singles + 5 stage-1 pairs + 5x7 refinement pairs
-    assert sum(" + " in l for l in convs) == 40
+    pw2 = [l for l in lines if l.startswith("step pw2")]
+    # 12 VGG/CPM singles + 5 stage-1 pairs + 5x7 refinement pairs = 52 launches, of which the six branch tails
+    # (1x1 -> 1x1: conv5_4/5_5 and Mconv6/Mconv7 of stages 2-6) are fused two layers per launch
+    assert len(convs) == 12 + 3 + 25 and len(pw2) == 6
+    assert sum(" + " in l for l in convs) == 28 and all(l.count(" + ") == 2 for l in pw2)
     assert any("conv4_4_CPM" in l and "dsts 6" in l for l in convs)  # own tensor + 5 concat slices
-    assert [l for l in convs if "Mconv7_stage6" in l][0].endswith("lowres 1")
+    assert [l for l in pw2 if "Mconv7_stage6" in l][0].endswith("lowres 1")
     assert sum(l.startswith("step pool") for l in lines) == 3
     # 3 scales: same graph, 3x the work
     l3 = _plan_lines(num_scales=3, scale_gap=0.15)
-    assert float(l3[-1].split()[1]) == pytest.approx(3 * 484.634, abs=3e-3)
+    assert float([l for l in l3 if l.startswith("conv_gflop")][0].split()[1]) == pytest.approx(3 * 484.634, abs=3e-3)
 
 
 def test_plan_mpi_and_errors():
@@ -315,7 +320,7 @@ def test_bit_exact_kernels_contain_no_packed_f32_valu():
     out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "caffe_rtpose_amd", "csrc"), "check-nopk"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     counts = [int(x) for x in out.stdout.split()]
-    assert counts == [0, 0, 0, 0, 0], out.stdout   # postproc, preproc, render, conv_ring, conv_igemm
+    assert counts == [0, 0, 0, 0, 0, 0], out.stdout   # postproc, preproc, render, conv_ring, conv_igemm, conv_pw2
 
 
 def test_caffemodel_blobshape_lengths_are_bounds_checked(tmp_path):
@@ -375,6 +380,7 @@ def test_split_precision_plan_and_rule_syntax():
     allx = r.plan_summary(r.Config(precision=r.PREC_F16X3))
     assert "passes 1 " not in allx.replace("passes 1 impl reg wgs 3784", "")   # conv1_1: image exact in fp16, weights split only
     s = r.plan_summary(r.Config(precision=r.PREC_MIXED, split_layers="conv4_4:w,*_stage6_L:a,@1x1"))
-    lines = {ln.split()[2]: ln for ln in s.splitlines() if ln.startswith("step conv")}
+    lines = {ln.split()[2]: ln for ln in s.splitlines() if ln.startswith(("step conv", "step pw2"))}
     assert " passes 2w " in lines["conv4_4_CPM"] and " passes 2a " in lines["Mconv2_stage6_L1"]
-    assert " passes 3aw " in lines["Mconv7_stage6_L1"] and " passes 1 " in lines["conv3_1"]
+    assert " passes 1 " in lines["conv3_1"]
+    assert " passes 3aw/3aw " in lines["Mconv6_stage6_L1"]   # the fused 1x1 pair: passes of the first / second layer
