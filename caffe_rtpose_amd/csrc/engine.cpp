@@ -136,6 +136,7 @@ struct Ctx {
   unsigned long long* ts_dev = nullptr;   // in-kernel {~start, end} stamps of the dominant-class launches of one replay
   unsigned long long* ts_host = nullptr;  // pinned copy, written by the graph after the conv stack
   int ts_n = 0;
+  unsigned char ts_pass[64] = {};         // MFMA passes (1..3) of the launch behind slot i
   bool ts_pending = false;
 };
 const int CTX_TS_SLOTS = 64;
@@ -178,6 +179,9 @@ struct rtp_engine {
   bool time_dominant = false;
   double dom_ms_total = 0;
   long dom_launches = 0;
+  double dom_ms_pass[4] = {0, 0, 0, 0};   // the same, by MFMA passes of the launch (split-precision layers run 2-3)
+  long dom_n_pass[4] = {0, 0, 0, 0};
+  std::vector<unsigned char> ts_ring_pass;
   // device-side pre-processing (row a1)
   const short* warp_tab_dev = nullptr;  // inside prep_tables
   std::vector<AreaScale> area_scales;   // device pointers inside prep_tables
@@ -594,6 +598,7 @@ int build_plan(rtp_engine* e) {
     if (s.type == 1 && e->convs[s.a].k == 7 && e->convs[s.a].cin == 128) { e->dominant_step = (int)si; break; }
   }
   e->strip_rows = 8;
+  if (const char* sr = getenv("RTP_NMS_STRIP_ROWS")) { const int v = atoi(sr); if (v >= 2 && v <= 16) e->strip_rows = v; }  // experiments
   e->nstrips = (e->cfg.net_h + e->strip_rows - 1) / e->strip_rows;
   e->max_rows = e->num_limbs * e->max_peaks;
   {
@@ -797,7 +802,8 @@ bool is_dominant_class(const rtp_engine* e, const Step& s) {
   if (s.type != 1 || e->dominant_step < 0) return false;
   const ConvOp& a = e->convs[s.a];
   const ConvOp& d = e->convs[e->steps[e->dominant_step].a];
-  return a.k == d.k && a.cin == d.cin && a.cout == d.cout && a.passes() == d.passes() && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
+  // every launch of the dominant kernel SYMBOL (what a profiler aggregates), whatever its number of MFMA passes
+  return a.k == d.k && a.cin == d.cin && a.cout == d.cout && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
 }
 
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bool cap = false) {
@@ -811,8 +817,9 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bo
     } else if (s.type == 1) {
       unsigned long long* ts = nullptr;
       if (e->time_dominant && is_dominant_class(e, s)) {
-        if (cap) { if (cx.ts_dev && cx.ts_n < CTX_TS_SLOTS) ts = cx.ts_dev + 2 * (size_t)cx.ts_n++; }
-        else if (e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS) ts = e->ts_ring + 2 * (size_t)e->ts_next++;
+        const unsigned char np = (unsigned char)e->convs[s.a].passes();
+        if (cap) { if (cx.ts_dev && cx.ts_n < CTX_TS_SLOTS) { cx.ts_pass[cx.ts_n] = np; ts = cx.ts_dev + 2 * (size_t)cx.ts_n++; } }
+        else if (e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS) { e->ts_ring_pass[e->ts_next] = np; ts = e->ts_ring + 2 * (size_t)e->ts_next++; }
       }
       const int rc = launch_conv_step(e, cx, s, nimg, ts);
       if (rc) return rc;
@@ -1501,7 +1508,11 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
     for (int i = 0; i < cx.ts_n; ++i) {
       const unsigned long long st = ~cx.ts_host[2 * i], en = cx.ts_host[2 * i + 1];
-      if (cx.ts_host[2 * i] != 0 && en > st) { e->dom_ms_total += (double)(en - st) / (double)khz; e->dom_launches++; }
+      if (cx.ts_host[2 * i] != 0 && en > st) {
+        const double ms = (double)(en - st) / (double)khz;
+        e->dom_ms_total += ms; e->dom_launches++;
+        e->dom_ms_pass[cx.ts_pass[i] & 3] += ms; e->dom_n_pass[cx.ts_pass[i] & 3]++;
+      }
     }
     cx.ts_pending = false;
   }
@@ -1941,7 +1952,11 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
     for (int i = 0; i < e->ts_next; ++i) {
       const unsigned long long st = ~h[2 * i], en = h[2 * i + 1];
-      if (h[2 * i] != 0 && en > st) { e->dom_ms_total += (double)(en - st) / (double)khz; e->dom_launches++; }
+      if (h[2 * i] != 0 && en > st) {
+        const double ms = (double)(en - st) / (double)khz;
+        e->dom_ms_total += ms; e->dom_launches++;
+        e->dom_ms_pass[e->ts_ring_pass[i] & 3] += ms; e->dom_n_pass[e->ts_ring_pass[i] & 3]++;
+      }
     }
     e->ts_next = 0;
   }
@@ -1958,14 +1973,25 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
   }
   if (enable >= 0) {
     if ((enable != 0) != e->time_dominant && !e->fifo.empty()) return fail(e, RTP_EAGAIN, "kernel timing can only be switched on an idle engine");
-    if ((enable != 0) != e->time_dominant || enable == 2) { e->dom_ms_total = 0; e->dom_launches = 0; }  // 2 = on + reset
+    if ((enable != 0) != e->time_dominant || enable == 2) {  // 2 = on + reset
+      e->dom_ms_total = 0; e->dom_launches = 0;
+      for (int i = 0; i < 4; ++i) { e->dom_ms_pass[i] = 0; e->dom_n_pass[i] = 0; }
+    }
     e->time_dominant = enable != 0;
     if (e->time_dominant) {
       if (!e->ts_ring) HIPCHK(e, hipMalloc((void**)&e->ts_ring, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
+      e->ts_ring_pass.assign(rtp_engine::TS_SLOTS, 1);
       HIPCHK(e, hipMemset(e->ts_ring, 0, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
       e->ts_next = 0;
     }
   }
+  return RTP_OK;
+}
+
+// Per-pass-count breakdown of rtp_kernel_timing's totals: ms[p], launches[p] for p = 1..3 MFMA passes (index 0 unused).
+int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches[4]) {
+  if (!e || !ms || !launches) return RTP_EINVAL;
+  for (int i = 0; i < 4; ++i) { ms[i] = e->dom_ms_pass[i]; launches[i] = e->dom_n_pass[i]; }
   return RTP_OK;
 }
 

@@ -22,6 +22,7 @@
 //            greedy assignment) and a single-wavefront assembly kernel that keeps the person
 //            table in LDS and parallelises the row searches over the 64 lanes.
 #include <atomic>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "stdsort_replica.h"
@@ -1063,7 +1064,8 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
   ConnectParams pa = p;
   {
     const size_t extra = 8 + ((size_t)p.num_parts * 3 * (p.max_peaks + 1) + (size_t)p.num_limbs * p.max_peaks * 3 + p.num_limbs) * 4;
-    pa.assemble_preload = (lds2 + extra <= 150 * 1024) ? 1 : 0;
+    static const char* np = getenv("RTP_ASSEMBLE_PRELOAD");  // experiments: 0 = no LDS copy of the assembly inputs
+    pa.assemble_preload = (lds2 + extra <= 150 * 1024 && !(np && np[0] == '0')) ? 1 : 0;
     if (pa.assemble_preload) lds2 += extra;
   }
   if (lds1 > 64 * 1024) {

@@ -439,6 +439,12 @@ class Engine:
         self._chk(lib.rtp_kernel_timing(self.h, enable, C.byref(tot), C.byref(n), C.byref(fl)))
         return tot.value, n.value, fl.value
 
+    def kernel_timing_by_passes(self):
+        ms = (C.c_double * 4)()
+        n = (C.c_long * 4)()
+        self._chk(lib.rtp_kernel_timing_by_passes(self.h, ms, n))
+        return {p: (ms[p], n[p]) for p in (1, 2, 3) if n[p]}
+
     def bench_dominant_conv(self, iters=50):
         ms = C.c_float()
         fl = C.c_double()

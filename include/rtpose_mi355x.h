@@ -260,6 +260,9 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
  * (what a profiler's kernel trace reports; stream events would also count the time a launch queues
  * behind other frames' kernels).  Call with an idle engine to harvest. */
 int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch);
+/* The same totals split by the number of MFMA passes of the launch (1 = plain fp16 layer, 3 = split-precision layer);
+ * index 0 is unused. */
+int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches[4]);
 
 /* Survivors of the PAF test (temp.size(), rtpose.cpp:950) and accepted connections
  * (connection_k.size(), :980) per limb for the last synchronous frame; arrays of num_limbs ints. */
