@@ -1196,7 +1196,7 @@ int rtp_config_default(rtp_config* cfg) {
   cfg->num_scales = 1;
   cfg->start_scale = 1.f; cfg->scale_gap = 0.3f;
   cfg->disp_w = 1280; cfg->disp_h = 720;
-  cfg->precision = RTP_PREC_FP16;
+  cfg->precision = RTP_PREC_MIXED;  // the fastest mode inside the north-star tolerance
   cfg->frames_in_flight = 2;
   cfg->batch_frames = 1;
   cfg->exec_mode = RTP_EXEC_GRAPH;

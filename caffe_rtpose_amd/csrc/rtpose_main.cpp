@@ -51,7 +51,7 @@ struct Flags {
   std::string resolution = "1280x720", net_resolution = "656x368", camera_resolution = "1280x720";
   double start_scale = 1, scale_gap = 0.3;
   // extensions (not in the reference)
-  std::string precision = "fp16", model = "";  // --model coco|mpi: use the built-in graph + synthetic weights
+  std::string precision = "mixed", model = "";  // --model coco|mpi: use the built-in graph + synthetic weights
   int frames_in_flight = 2, batch_frames = 1;
   unsigned long long synthetic_seed = 1;
   std::string devices;           // "0,0,1": device of worker i (default start_device + i); lets two workers share one GPU
@@ -105,7 +105,7 @@ void usage() {
          "  --caffeproto FILE --caffemodel FILE   | --model coco|mpi (built-in graph, synthetic weights)\n"
          "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
          "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
-         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision fp16|fp32 --frames_in_flight K --batch_frames B --host_preprocess\n"
+         "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision mixed|fp16|f16x3|fp32 --frames_in_flight K --batch_frames B --host_preprocess\n"
          "   --devices d0,d1,.. (device of each worker; the same device may appear twice)]\n");
 }
 
@@ -253,7 +253,7 @@ void worker(int widx, int device, int* status) {
   cfg.net_w = NET_W; cfg.net_h = NET_H; cfg.num_scales = F.num_scales;
   cfg.start_scale = (float)F.start_scale; cfg.scale_gap = (float)F.scale_gap;
   cfg.disp_w = DISP_W; cfg.disp_h = DISP_H;
-  cfg.precision = F.precision == "fp32" ? RTP_PREC_FP32 : RTP_PREC_FP16;
+  cfg.precision = F.precision == "fp32" ? RTP_PREC_FP32 : F.precision == "fp16" ? RTP_PREC_FP16 : F.precision == "f16x3" ? RTP_PREC_F16X3 : RTP_PREC_MIXED;
   cfg.frames_in_flight = F.frames_in_flight;
   cfg.batch_frames = F.batch_frames;
   cfg.render = F.write_frames.empty() ? 0 : 1;
@@ -465,6 +465,7 @@ int main(int argc, char** argv) {
   for (const std::string* d : {&F.write_frames, &F.write_json})
     if (!d->empty() && !mkdir_p(*d)) { fprintf(stderr, "Could not write to or create directory %s\n", d->c_str()); return 1; }
   if (F.num_gpu < 1) { fprintf(stderr, "--num_gpu must be >= 1\n"); return 1; }
+  if (F.precision != "mixed" && F.precision != "fp16" && F.precision != "f16x3" && F.precision != "fp32") { fprintf(stderr, "--precision must be mixed, fp16, f16x3 or fp32\n"); return 1; }
   if (F.frames_in_flight < 1 || F.frames_in_flight > 64) { fprintf(stderr, "--frames_in_flight must be in [1, 64]\n"); return 1; }
   if (F.batch_frames < 1 || F.batch_frames > 16) { fprintf(stderr, "--batch_frames must be in [1, 16]\n"); return 1; }
   std::vector<int> devs;

@@ -39,7 +39,7 @@ extern "C" {
 #define RTP_MODEL_COCO_18 0 /* ModelDescriptorFactory::Type::COCO_18 (modelDescriptorFactory.cpp:30) */
 #define RTP_MODEL_MPI_15 1  /* ModelDescriptorFactory::Type::MPI_15  (modelDescriptorFactory.cpp:6)  */
 
-#define RTP_PREC_FP16 0 /* fp16 storage, MFMA f16 with fp32 accumulate (headline path)      */
+#define RTP_PREC_FP16 0 /* fp16 storage, MFMA f16 with fp32 accumulate: fastest, 2-2.6x OUTSIDE +-1e-3 */
 #define RTP_PREC_FP32 1 /* fp32 storage, exact-f32 MFMA (parity path, 1/16 the MFMA rate)   */
 #define RTP_PREC_MIXED 2 /* fp16 MFMA; the layers named by split_layers (default: the set whose fp16 rounding   *
                           * dominates the final-map error) run SPLIT: activations and weights as hi + lo fp16   *
@@ -89,7 +89,7 @@ typedef struct rtp_config {
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
- * start_scale 1, scale_gap 0.3, 1280x720, fp16, 2 frames in flight. */
+ * start_scale 1, scale_gap 0.3, 1280x720, RTP_PREC_MIXED, 2 frames in flight, graph replay. */
 int rtp_config_default(rtp_config* cfg);
 
 /* Replaces: new Net<float>(proto, TEST) + CopyTrainedLayersFrom + Reshape + dry run

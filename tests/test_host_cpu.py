@@ -50,6 +50,7 @@ def test_config_defaults_are_the_reference_flag_defaults():
     c = r.Config().c
     assert (c.net_w, c.net_h, c.disp_w, c.disp_h, c.num_scales) == (656, 368, 1280, 720, 1)
     assert c.start_scale == 1.0 and abs(c.scale_gap - 0.3) < 1e-7
+    assert c.precision == r.PREC_MIXED and c.exec_mode == r.EXEC_GRAPH   # the mode that meets the +-1e-3 tolerance; captured launch plan
 
 
 def test_model_tables_and_thresholds_match_oracle():
@@ -71,7 +72,9 @@ def test_plan_coco_flops_and_pairing():
     assert lines[0] == "model 0 parts 18 max_peaks 64 heat_channels 57"
     gf = {l.split()[0]: float(l.split()[1]) for l in lines if l.startswith(("conv_gflop", "mfma_gflop"))}
     assert gf["conv_gflop"] == pytest.approx(484.634, abs=1e-3)
-    assert gf["mfma_gflop"] == pytest.approx(484.634, abs=1e-3)  # fp16: one MFMA pass per layer
+    assert gf["mfma_gflop"] == pytest.approx(1139.45, abs=1e-2)   # default precision (mixed): split layers run three MFMA passes
+    fp16 = _plan_lines(precision=0)
+    assert float([l for l in fp16 if l.startswith("mfma_gflop")][0].split()[1]) == pytest.approx(484.634, abs=1e-3)
     convs = [l for l in lines if l.startswith("step conv")]
     pw2 = [l for l in lines if l.startswith("step pw2")]
     # 12 VGG/CPM singles + 5 stage-1 pairs + 5x7 refinement pairs = 52 launches, of which the six branch tails
@@ -90,7 +93,7 @@ def test_plan_mpi_and_errors():
     import caffe_rtpose_amd as r
     lines = _plan_lines(model=1, net_w=496, net_h=368)
     assert lines[0] == "model 1 parts 15 max_peaks 20 heat_channels 44"
-    assert float(lines[-1].split()[1]) == pytest.approx(361.695, abs=1e-3)
+    assert float([l for l in lines if l.startswith("conv_gflop")][0].split()[1]) == pytest.approx(361.695, abs=1e-3)
     with pytest.raises(r.RtpError):
         _plan_lines(net_w=650)  # not a multiple of 16
     with pytest.raises(r.RtpError):
