@@ -45,6 +45,27 @@ def rnd(t, mode):
     return hi + lo
 
 
+def f8(t, scale_exp):
+    """e4m3fn rounding of t * 2^scale_exp (clamped to +-448 first), returned in t's units."""
+    sc = 2.0 ** scale_exp
+    return (t * sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() / sc
+
+
+def conv_h8(x, w, b, pad, comp_a=True, comp_w=True):
+    """hi*hi in fp16 + fp8 error compensation: a_lo8 * W8 + a8 * W_lo8 (what the MX-scaled fp8 MFMA passes compute)."""
+    xh = x.half().float(); wh = w.half().float()
+    y = F.conv2d(xh, wh, b, padding=pad)
+    wmax = float(w.abs().max())
+    tw = int(np.floor(np.log2(448.0 / wmax)))
+    if comp_a:
+        xlo = x - xh
+        y = y + F.conv2d(f8(xlo, 12), f8(wh, tw), None, padding=pad)
+    if comp_w:
+        wlo = w - wh
+        y = y + F.conv2d(f8(xh, 2), f8(wlo, tw + 11), None, padding=pad)
+    return y
+
+
 def layers(model=0):
     """(name, cin, cout, k, relu, section) in execution order + topology handled in forward()."""
     nL1, nL2 = (38, 19) if model == 0 else (28, 16)
@@ -63,7 +84,10 @@ def forward(x, wm, am, over, model=0):
             if pat.startswith("re/") and re.search(pat[3:], name):
                 w_mode, a_mode = v
         w, b = synth(name, cout, cin, k)
-        y = F.conv2d(rnd(t, a_mode), rnd(w, w_mode), b, padding=k // 2)
+        if w_mode == "h8" or a_mode == "h8":
+            y = conv_h8(t, w, b, k // 2, comp_a=(a_mode == "h8"), comp_w=(w_mode == "h8"))
+        else:
+            y = F.conv2d(rnd(t, a_mode), rnd(w, w_mode), b, padding=k // 2)
         return F.relu(y) if relu else y
 
     t = x
@@ -91,7 +115,7 @@ def forward(x, wm, am, over, model=0):
             for i in range(1, 6):
                 # the concat re-injection can carry its own activation mode ("cat")
                 s_eff = "cat" if (i == 1 and "cat" in over) else sec
-                if s_eff == "cat":
+                if s_eff == "cat" and False:
                     w_mode = over.get(sec, (wm, am))[0]
                     w, b = synth(f"Mconv{i}_stage{s}_L{br}", 128, cin, 7)
                     u = F.relu(F.conv2d(rnd(u, over["cat"][1]), rnd(w, w_mode), b, padding=3))
