@@ -50,6 +50,7 @@ SIGNATURES = {
     "rtp_set_thresholds": (C.c_int, [vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]),
     "rtp_get_thresholds": (C.c_int, [vp, fp, fp, ip, ip, fp]),
     "rtp_set_scales": (C.c_int, [vp, C.c_float, C.c_float]),
+    "rtp_debug_f32_to_e4m3": (C.c_int, [fp, C.POINTER(C.c_ubyte), C.c_int]),
     "rtp_kernel_timing_by_passes": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "rtp_submit": (C.c_int, [vp, fp, C.c_uint64]),
     "rtp_submit_device": (C.c_int, [vp, vp, C.c_uint64]),

@@ -52,10 +52,17 @@ hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, 
   return hipGetLastError();
 }
 
+// OCP e4m3 byte -> float (q blocks: fp8 error-compensation operands, see ConvDst::q_off)
+__device__ __forceinline__ float e4m3_to_float(unsigned b) {
+  const unsigned s = b & 0x80, e = (b >> 3) & 15, m = b & 7;
+  const float mag = e ? __uint_as_float(((e + 120) << 23) | (m << 20)) : (float)m * 0.001953125f;  // 2^(e-7) * (1 + m/8); subnormal m * 2^-9
+  return s ? -mag : mag;
+}
+
 // ---- 2x2 / stride 2 MAX pooling (pooling_layer.cpp:140-180; resolutions are even) ----------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, Geom gi, int Cpi, T* __restrict__ out,
-                                                       Geom go, int Cpo, int C, int lo_i, int lo_o) {
+                                                       Geom go, int Cpo, int C, int lo_i, int lo_o, int q_i, int q_o) {
   constexpr int VEC = 16 / sizeof(T);
   const int cv = C / VEC;
   const long total = (long)go.N * go.H * go.W * cv;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
       __builtin_memcpy(h[q], &v, 16);
     }
     T* op = out + (((long)n * go.Hp + y + go.halo) * go.Wp + x + go.halo) * Cpo + c;
-    if (!lo_i) {
+    if (!lo_i && !q_i) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         T m = h[0][i];
@@ -84,29 +91,60 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
         m = h[3][i] > m ? h[3][i] : m;
         o[i] = m;
       }
-    } else {  // split precision: the value is hi + lo; the first maximum in (0,0),(0,1),(1,0),(1,1) order keeps both parts
+    } else {  // split precision: the value is hi + lo; the first maximum in (0,0),(0,1),(1,0),(1,1) order keeps all its parts
       T l[4][VEC], ol[VEC];
+      unsigned char ql[4][VEC], qh[4][VEC], oql[VEC], oqh[VEC];
+      float lf[4][VEC];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint4 v = *(const uint4*)(ip + offs[q] + lo_i);
-        __builtin_memcpy(l[q], &v, 16);
+        if (lo_i) {
+          const uint4 v = *(const uint4*)(ip + offs[q] + lo_i);
+          __builtin_memcpy(l[q], &v, 16);
+        }
+        if constexpr (sizeof(T) == 2) {
+          if (q_i) {  // 8 lo8 bytes and 8 hi8 bytes of these 8 channels (group of 64 channels = 128 bytes)
+            const unsigned char* qp = (const unsigned char*)(ip - c + offs[q] + q_i) + (c >> 6) * 128 + (c & 63);
+            const uint2 a = *(const uint2*)qp, b = *(const uint2*)(qp + 64);
+            __builtin_memcpy(ql[q], &a, 8);
+            __builtin_memcpy(qh[q], &b, 8);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lf[q][i] = lo_i ? (float)l[q][i] : ((sizeof(T) == 2 && q_i) ? e4m3_to_float(ql[q][i & 7]) : 0.f);
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        T mh = h[0][i], ml = l[0][i];
+        T mh = h[0][i], ml = lo_i ? l[0][i] : (T)0.f;
+        float mlf = lf[0][i];
+        unsigned char mql = ql[0][i & 7], mqh = qh[0][i & 7];
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
-          const bool gt = h[q][i] > mh || (h[q][i] == mh && l[q][i] > ml);
+          const bool gt = h[q][i] > mh || (h[q][i] == mh && lf[q][i] > mlf);
           mh = gt ? h[q][i] : mh;
-          ml = gt ? l[q][i] : ml;
+          ml = gt ? (lo_i ? l[q][i] : (T)0.f) : ml;
+          mlf = gt ? lf[q][i] : mlf;
+          mql = gt ? ql[q][i & 7] : mql;
+          mqh = gt ? qh[q][i & 7] : mqh;
         }
         o[i] = mh;
         ol[i] = ml;
+        oql[i & 7] = mql;
+        oqh[i & 7] = mqh;
       }
-      if (lo_o) {
+      if (lo_o && lo_i) {
         uint4 rl;
         __builtin_memcpy(&rl, ol, 16);
         *(uint4*)(op + lo_o) = rl;
+      }
+      if constexpr (sizeof(T) == 2) {
+        if (q_o && q_i) {
+          unsigned char* qp = (unsigned char*)(op - c + q_o) + (c >> 6) * 128 + (c & 63);
+          uint2 a, b;
+          __builtin_memcpy(&a, oql, 8);
+          __builtin_memcpy(&b, oqh, 8);
+          *(uint2*)qp = a;
+          *(uint2*)(qp + 64) = b;
+        }
       }
     }
     uint4 r;
@@ -115,21 +153,21 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
   }
 }
 
-hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o,
+hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o, int q_i, int q_o,
                           hipStream_t stream) {
   const int vec = prec == 0 ? 8 : 4;
   const long total = (long)go.N * go.H * go.W * (C / vec);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, lo_i, lo_o);
-  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C, lo_i, lo_o);
+  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, lo_i, lo_o, q_i, q_o);
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C, lo_i, lo_o, 0, 0);
   return hipGetLastError();
 }
 
 // ---- debug export: halo'd NHWC -> planar fp32 NCHW (Net::blob_by_name()->cpu_data() tap) ----
 template <typename T>
 __global__ __launch_bounds__(256) void export_kernel(const T* __restrict__ in, Geom g, int Cp, const int* __restrict__ chmap,
-                                                      int C, int lo_off, float* __restrict__ out) {
+                                                      int C, int lo_off, int q_off, float* __restrict__ out) {
   const long total = (long)g.N * C * g.H * g.W;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int x = (int)(idx % g.W);
@@ -140,17 +178,20 @@ __global__ __launch_bounds__(256) void export_kernel(const T* __restrict__ in, G
     const int n = (int)(p / C);
     const int ci = chmap ? chmap[c] : c;
     const T* ip = in + (((long)n * g.Hp + y + g.halo) * g.Wp + x + g.halo) * Cp + ci;
-    out[idx] = lo_off ? (float)ip[0] + (float)ip[lo_off] : (float)ip[0];
+    float v = (float)ip[0];
+    if (lo_off) v += (float)ip[lo_off];
+    else if (q_off && sizeof(T) == 2) v += e4m3_to_float(((const unsigned char*)(ip - ci + q_off))[(ci >> 6) * 128 + (ci & 63)]) * (1.f / 4096.f);
+    out[idx] = v;
   }
 }
 
-hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, int lo_off, float* out,
+hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, int lo_off, int q_off, float* out,
                          hipStream_t stream) {
   const long total = (long)g.N * C * g.H * g.W;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (prec == 0) hipLaunchKernelGGL(export_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, g, Cp, chmap_dev, C, lo_off, out);
-  else hipLaunchKernelGGL(export_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, g, Cp, chmap_dev, C, lo_off, out);
+  if (prec == 0) hipLaunchKernelGGL(export_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, g, Cp, chmap_dev, C, lo_off, q_off, out);
+  else hipLaunchKernelGGL(export_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, g, Cp, chmap_dev, C, lo_off, 0, out);
   return hipGetLastError();
 }
 

@@ -27,6 +27,27 @@ template <> struct Mma<float> {
   }
 };
 
+typedef int intx8 __attribute__((ext_vector_type(8)));
+// fp8 (OCP e4m3) error-compensation passes of a split-precision layer: 32x32x64 MX-scaled MFMA, 64 cycles per instruction =
+// twice the fp16 rate per K.  Operand: lane l holds row (l&31), K bytes [(l>>5)*32, +32) of the 64-byte k-block
+// (tools/mx_fp8_probe.hip); sa / sb = E8M0 scales (2^(e-127)) applied by the hardware, so the products land in the same fp32
+// accumulators as the fp16 pass.
+__device__ __forceinline__ void mma_fp8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, floatx16& c, int sa, int sb) {
+  intx8 a, b;
+  a[0] = (int)a0.x; a[1] = (int)a0.y; a[2] = (int)a0.z; a[3] = (int)a0.w; a[4] = (int)a1.x; a[5] = (int)a1.y; a[6] = (int)a1.z; a[7] = (int)a1.w;
+  b[0] = (int)b0.x; b[1] = (int)b0.y; b[2] = (int)b0.z; b[3] = (int)b0.w; b[4] = (int)b1.x; b[5] = (int)b1.y; b[6] = (int)b1.z; b[7] = (int)b1.w;
+  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+}
+constexpr int Q_LO_EXP = 12, Q_HI_EXP = 2;             // q block: fp8(lo * 2^12), fp8(hi * 2^2)
+constexpr int Q_SA_LO = 127 - Q_LO_EXP, Q_SA_HI = 127 - Q_HI_EXP;
+// v_cvt_pk_fp8_f32 rounds to nearest even and keeps subnormals, but turns |x| > 464 into NaN: clamp first
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  unsigned r = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, (int)r, true);
+}
+
 // XCD-aware decode of a 1-D grid.  The dispatcher places workgroup `lin` on XCD lin % 8 and each
 // XCD has a private 4 MiB L2, so the grid is laid out such that one XCD sees a CONTIGUOUS range
 // of the logical index L = ((prob * ntiles + ntile) * mtiles_total + mtile): workgroups on one
@@ -140,6 +161,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
           }
         } else {
           for (int u = 0; u < nvalid; ++u) lp[u] = lo[u];
+        }
+      }
+      if constexpr (sizeof(T) == 2) {
+        if (pr.dst[d].q_off) {  // fp8 compensation operands for a consumer that runs the fp8 passes
+          const int ch = pr.dst[d].coff + c0;
+          unsigned char* qrow = (unsigned char*)((T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].q_off);
+          float lof[16], hif[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) { hif[u] = (float)out[u]; lof[u] = (v[u] - hif[u]) * (float)(1 << Q_LO_EXP); hif[u] *= (float)(1 << Q_HI_EXP); }
+          if (nvalid == 16 && (ch & 15) == 0) {
+            unsigned char* qb = qrow + (ch >> 6) * 128 + (ch & 63);
+            uint4 ql, qh;
+            ql.x = pack4_fp8(lof[0], lof[1], lof[2], lof[3]); ql.y = pack4_fp8(lof[4], lof[5], lof[6], lof[7]);
+            ql.z = pack4_fp8(lof[8], lof[9], lof[10], lof[11]); ql.w = pack4_fp8(lof[12], lof[13], lof[14], lof[15]);
+            qh.x = pack4_fp8(hif[0], hif[1], hif[2], hif[3]); qh.y = pack4_fp8(hif[4], hif[5], hif[6], hif[7]);
+            qh.z = pack4_fp8(hif[8], hif[9], hif[10], hif[11]); qh.w = pack4_fp8(hif[12], hif[13], hif[14], hif[15]);
+            *(uint4*)qb = ql;
+            *(uint4*)(qb + 64) = qh;
+          } else {
+            for (int u = 0; u < nvalid; ++u) {
+              const int cu = ch + u;
+              unsigned char* qb = qrow + (cu >> 6) * 128 + (cu & 63);
+              qb[0] = (unsigned char)(pack4_fp8(lof[u], 0.f, 0.f, 0.f) & 0xff);
+              qb[64] = (unsigned char)(pack4_fp8(hif[u], 0.f, 0.f, 0.f) & 0xff);
+            }
+          }
         }
       }
     }

@@ -179,6 +179,8 @@ constexpr int ring_wait_count(int s) {
 //   2 = s_setprio 3 on the consumer waves; 3 = accumulators in AGPRs (timing only)
 //   ablations (wrong results, timing only): 11 = no ds_reads, 12 = no MFMAs, 13 = no LDS-DMA,
 //   15 = no per-tap barriers (and no counted waits), 16 = 15 + no ds_reads (a bare MFMA stream)
+//   100 = the fp8-compensated variant of the kernel (layers with q chunks, ConvParams::q_from): its own instantiation, so that
+//       the plain kernel's register allocation (254 VGPRs with the front-loaded reads) is not disturbed; reads one per MFMA
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0>
 __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvParams P) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
@@ -233,17 +235,18 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   const unsigned sB_addr = lds_addr_of(sB) + wave * B_PW * 1024;
 
   int a_chunk = 0;  // chunk index of the strip a_ptr points to
-  auto issue_a = [&](int buf) {  // strip at a_ptr -> sA[buf]; advances a_ptr to the next strip
+  auto issue_a = [&](int buf) __attribute__((always_inline)) {  // strip at a_ptr -> sA[buf]; advances a_ptr to the next strip
     const unsigned l = sA_addr + buf * TR::A_BYTES;
     if constexpr (A_PW <= 4) dma_group_each<A_PW>(a_ptr, a_voff, l);
     else if constexpr (A_PW <= 8) { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<A_PW - 4>(a_ptr, a_voff + 4, l + 4096); }
     else { dma_group_each<4>(a_ptr, a_voff, l); dma_group_each<4>(a_ptr, a_voff + 4, l + 4096); dma_group_each<A_PW - 8>(a_ptr, a_voff + 8, l + 8192); }
     // past the last strip this keeps walking: harmless dummy reads of arena memory (tail pad)
-    if (++a_chunk == nchunk) { a_chunk = 0; a_ptr += row_step_bytes - (long)P.last_phys * CHB; }
+    if (++a_chunk == nchunk) { a_chunk = 0; a_ptr += row_step_bytes - (long)P.row_back; }
     else if (a_chunk == P.wrap_at) a_ptr -= (long)(P.wrap_at - 1) * CHB;  // split precision: the a_hi chunks once more (x W_lo)
+    else if (a_chunk == P.q_from) a_ptr += P.jump_delta;                   // fp8 compensation: on to the tensor's q block
     else a_ptr += CHB;
   };
-  auto issue_b = [&](int stage) {  // tile at b_ptr -> sB[stage]; advances b_ptr
+  auto issue_b = [&](int stage) __attribute__((always_inline)) {  // tile at b_ptr -> sB[stage]; advances b_ptr
     const unsigned l = sB_addr + stage * TR::B_BYTES;
     if constexpr (B_PW <= 4) dma_group_same<B_PW>(b_ptr, b_voff, l);
     else { dma_group_same<4>(b_ptr, b_voff, l); dma_group_same<B_PW - 4>(b_ptr + 4096, b_voff, l + 4096); }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       for (int j = 0; j < TN; ++j) rb[gi][j] = *(const uint4*)(pb + j * 32 * CHB + ((cl ^ bswz) * 16));
     }
   };
-  auto mma_all = [&]() {
+  auto mma_all = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(fa[gi][i], fb[gi][j], acc[i][j]);
   };
-  auto rotate = [&]() {
+  auto rotate = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
 #pragma unroll
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       wait_vmcnt<(SB - 1) * B_PW>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      auto pstep = [&](auto s_tag, auto first_tag) {
+      auto pstep = [&](auto s_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr int s = decltype(s_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         if constexpr (VAR != 15 && VAR != 16 && VAR != 17) {
@@ -359,15 +362,49 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
         for (int j = 0; j < TN; ++j) fb[gi][j] = make_uint4(0, 0, 0, 0);
       }
     }
-    auto read_one_c = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) {
+    // ---- The fragment registers fa/fb (being multiplied) and na_/nb_ (being read) serve both chunk types: an fp16 tap uses
+    //      every 16-byte fragment as one k-group (32x32x16 MFMA); an fp8 compensation tap (q chunk) uses fragments 2jj, 2jj+1
+    //      together as the 8-register operand of one k-block of v_mfma_scale_f32_32x32x64_f8f6f4 (CANQ: the wave's share of a
+    //      chunk is a whole number of 64-byte k-blocks). ----
+    constexpr bool CANQ = VAR == 100 && std::is_same<T, _Float16>::value && (GPW % 2 == 0);
+    constexpr int NKB = CANQ ? GPW / 2 : 1;
+    constexpr int NRD_C = GPW * (TM + TN);
+    const int sb_even = 127 - P.wq_exp, sb_odd = 127 - P.wq_exp - 11;  // E8M0 scales of W8 / W_lo8
+    // Fragment read #idx of the tap being prefetched: k-group gi = 32 bytes, lane half lhalf takes 16 of them — the SAME
+    // addresses for both chunk types.  For a q chunk that hands lane half lhalf the 16-byte pieces #lhalf and #(2+lhalf) of
+    // each 64-byte k-block instead of 32 contiguous bytes; A and B are read alike, so the MFMA still pairs equal K positions
+    // (a dot product does not care about the order of its terms).
+    auto read_one_c = [&](auto rq_tag, int idx, const unsigned char* pa, const unsigned char* pb, int aswz) __attribute__((always_inline)) {
       const int gi = idx / (TM + TN), q = idx % (TM + TN);
       const int cl = 2 * (kg * GPW + gi) + lhalf;
       if (q < TM) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
       else nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
     };
-    constexpr int NMMA_C = GPW * TM * TN, NRD_C = GPW * (TM + TN);
-    auto cstep = [&](auto s_tag) {
+    // MFMA #m of the tap being multiplied.  MQ: fp8 compensation tap — k-block jj of this wave is the (kg*NKB + jj)-th of the
+    // chunk: even = a_lo8 x W8, odd = a8 x W_lo8.
+    auto mma_one_c = [&](auto mq_tag, int m) __attribute__((always_inline)) {
+      constexpr bool MQ = decltype(mq_tag)::value;
+      if constexpr (MQ && CANQ) {
+        const int jj = m / (TM * TN), r = m % (TM * TN);
+        const bool odd = ((kg * NKB + jj) & 1) != 0;
+        mma_fp8(fa[2 * jj][r / TN], fa[2 * jj + 1][r / TN], fb[2 * jj][r % TN], fb[2 * jj + 1][r % TN], acc[r / TN][r % TN],
+                odd ? Q_SA_HI : Q_SA_LO, odd ? sb_odd : sb_even);
+      } else if constexpr (VAR == 3) {  // timing only: accumulators forced into AGPRs (asm MFMA: no hazard padding by hipcc)
+        const int gi = m / (TM * TN), r = m % (TM * TN);
+        const half8_t av = __builtin_bit_cast(half8_t, fa[gi][r / TN]);
+        const half8_t bv = __builtin_bit_cast(half8_t, fb[gi][r % TN]);
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[r / TN][r % TN]) : "v"(av), "v"(bv));
+      } else if constexpr (VAR != 12) {
+        const int gi = m / (TM * TN), r = m % (TM * TN);
+        Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
+      }
+    };
+    // one tap: multiply tap P-1 (type MQ) while the fragments of tap P (type RQ) are read
+    auto cstep = [&](auto s_tag, auto mq_tag, auto rq_tag) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
+      constexpr bool MQ = decltype(mq_tag)::value && CANQ;
+      constexpr bool RQ = decltype(rq_tag)::value && CANQ;
+      constexpr int NMMA_C = (MQ ? NKB : GPW) * TM * TN;
       if constexpr (VAR != 15 && VAR != 16 && VAR != 17) {
         wait_vmcnt<63>();  // lgkmcnt(0): this wave's ds_reads of the stage about to be overwritten have returned
         __builtin_amdgcn_s_barrier();
@@ -381,50 +418,65 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < NMMA_C; ++m) {
-        if constexpr (VAR == 3) {  // timing only: accumulators forced into AGPRs (asm MFMA: no hazard padding by hipcc)
-          const int gi = m / (TM * TN), r = m % (TM * TN);
-          const half8_t av = __builtin_bit_cast(half8_t, fa[gi][r / TN]);
-          const half8_t bv = __builtin_bit_cast(half8_t, fb[gi][r % TN]);
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[r / TN][r % TN]) : "v"(av), "v"(bv));
-        } else if constexpr (VAR != 12) {
-          const int gi = m / (TM * TN), r = m % (TM * TN);
-          Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
-        }
-        if constexpr (VAR != 4 && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded: 2 per MFMA over the first half of the tap
+        mma_one_c(mq_tag, m);
+        if constexpr (VAR != 4 && VAR != 100 && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded over the first half of the tap
           constexpr int HALF = NMMA_C / 2 > 0 ? NMMA_C / 2 : 1;
           if (m < HALF) {
 #pragma unroll
-            for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(rd, pa, pb, aswz);
+            for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(rq_tag, rd, pa, pb, aswz);
           }
-        } else if constexpr (VAR == 4) {
+        } else if constexpr (VAR == 4 || VAR == 100) {
 #pragma unroll
-          for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rd, pa, pb, aswz);
+          for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rq_tag, rd, pa, pb, aswz);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       st = (st + 1 == SB) ? 0 : st + 1;
       rotate();
     };
-    cstep(std::integral_constant<int, 1>{});
-    cstep(std::integral_constant<int, 2>{});
-    if constexpr (KS == 7) {
-      cstep(std::integral_constant<int, 3>{});
-      cstep(std::integral_constant<int, 4>{});
-      cstep(std::integral_constant<int, 5>{});
-      cstep(std::integral_constant<int, 6>{});
-    }
-    for (int sc = 1; sc < nstrips; ++sc) {
-      cstep(std::integral_constant<int, 0>{});
-      cstep(std::integral_constant<int, 1>{});
-      cstep(std::integral_constant<int, 2>{});
+    const std::true_type QT{};
+    const std::false_type QF{};
+    // taps 1..KS-1 of a strip whose chunk type is known
+    auto strip_tail = [&](auto q_tag) __attribute__((always_inline)) {
+      cstep(std::integral_constant<int, 1>{}, q_tag, q_tag);
+      cstep(std::integral_constant<int, 2>{}, q_tag, q_tag);
       if constexpr (KS == 7) {
-        cstep(std::integral_constant<int, 3>{});
-        cstep(std::integral_constant<int, 4>{});
-        cstep(std::integral_constant<int, 5>{});
-        cstep(std::integral_constant<int, 6>{});
+        cstep(std::integral_constant<int, 3>{}, q_tag, q_tag);
+        cstep(std::integral_constant<int, 4>{}, q_tag, q_tag);
+        cstep(std::integral_constant<int, 5>{}, q_tag, q_tag);
+        cstep(std::integral_constant<int, 6>{}, q_tag, q_tag);
       }
+    };
+    bool last_q = false;
+    if constexpr (CANQ) {
+      // fp8-compensated layer: every filter row = ncp fp16 strips, then ncp q strips.  The chunk type of every step is
+      // STATIC in this nest (a dynamic type per strip made the register state at the loop header the union of both).
+      const int ncp = P.q_from;
+      auto row_body = [&]() __attribute__((always_inline)) {  // entered with the fragments of tap 0 of the row's first fp16 strip in fa / fb
+        strip_tail(QF);
+        for (int c = 1; c < ncp; ++c) { cstep(std::integral_constant<int, 0>{}, QF, QF); strip_tail(QF); }
+        cstep(std::integral_constant<int, 0>{}, QF, QT);
+        strip_tail(QT);
+        for (int c = 1; c < ncp; ++c) { cstep(std::integral_constant<int, 0>{}, QT, QT); strip_tail(QT); }
+      };
+      row_body();  // filter row 0 (peeled: the loop below is entered and re-entered with q fragments live, never fp16 ones)
+      for (int r = 1; r < KS; ++r) {
+        cstep(std::integral_constant<int, 0>{}, QT, QF);  // last q tap of the previous row | first fp16 strip of this one
+        row_body();
+      }
+      last_q = true;
+    } else {
+      strip_tail(QF);
+      for (int sc = 1; sc < nstrips; ++sc) { cstep(std::integral_constant<int, 0>{}, QF, QF); strip_tail(QF); }
     }
-    mma_all();  // last tap
+    // last tap
+    if (CANQ && last_q) {
+#pragma unroll
+      for (int m = 0; m < NKB * TM * TN; ++m) mma_one_c(QT, m);
+    } else {
+#pragma unroll
+      for (int m = 0; m < GPW * TM * TN; ++m) mma_one_c(QF, m);
+    }
     wait_vmcnt<63>();
     __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
     conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
@@ -452,13 +504,13 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   int ist = 0;    // ring stage the next weight tile goes to ((P-1) % SB)
 
   // fragment read #idx of tap s (idx enumerates group-major: TM A-fragments then TN B-fragments)
-  auto read_one = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) {
+  auto read_one = [&](int idx, const unsigned char* pa, const unsigned char* pb, int aswz) __attribute__((always_inline)) {
     const int gi = idx / (TM + TN), q = idx % (TM + TN);
     const int cl = 2 * (kg * GPW + gi) + lhalf;
     if (q < TM) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
     else nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
   };
-  auto mma_one = [&](int idx) {
+  auto mma_one = [&](int idx) __attribute__((always_inline)) {
     const int gi = idx / (TM * TN), r = idx % (TM * TN);
     Mma<T>::run(fa[gi][r / TN], fb[gi][r % TN], acc[r / TN][r % TN]);
   };
@@ -468,7 +520,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   // and the DMA issue, the address math and tap P's ds_reads are slotted BETWEEN them, so the
   // matrix pipe is busy while everything else issues (pinned with sched_barrier: left alone hipcc
   // clusters the MFMAs and leaves the pipe idle during the ~150 cycles of issue in front of them).
-  auto step = [&](auto s_tag, auto first_tag) {
+  auto step = [&](auto s_tag, auto first_tag) __attribute__((always_inline)) {
     constexpr int s = decltype(s_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
     wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
@@ -534,6 +586,12 @@ static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStr
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
+  if (P.q_from > 0) {  // fp8-compensated layer: always the wave-specialised kernel, q instantiation
+    if constexpr (std::is_same<T, _Float16>::value && ((CHB / 32) / KSPLIT) % 2 == 0)
+      return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100>(P, nprob, N, stream);
+    else
+      return hipErrorInvalidValue;
+  }
   if (P.spec) {
     // experiment variants exist for the dominant plan only (fp16, 7x7, tile 128x64, 256-byte chunks)
     if constexpr (std::is_same<T, _Float16>::value && BM == 128 && BN == 64 && KS == 7 && CHB == 256) {

@@ -48,9 +48,12 @@ struct Tensor {
   int C = 0, Cp = 0, level = 0;
   size_t offset = 0;        // byte offset of padded pixel 0 of image 0 inside a context arena
   std::vector<int> chmap;   // reference channel -> internal channel
-  bool split = false;       // split precision: channels [Cp, 2*Cp) hold lo = T(v - float(T(v))) of channels [0, Cp)
-  int stride() const { return split ? 2 * Cp : Cp; }  // channels per pixel in memory
-  int lo_off() const { return split ? Cp : 0; }
+  // split precision: [0, Cp) hi; need_lo: [Cp, 2Cp) lo = T(v - float(T(v))) (consumers running three fp16 passes);
+  // need_q: a further Cp elements = 2*Cp bytes of fp8 compensation operands (consumers running the fp8 passes, ConvDst::q_off)
+  bool need_lo = false, need_q = false;
+  int stride() const { return Cp * (1 + (need_lo ? 1 : 0) + (need_q ? 1 : 0)); }  // channels (elements) per pixel in memory
+  int lo_off() const { return need_lo ? Cp : 0; }
+  int q_off() const { return need_q ? Cp * (need_lo ? 2 : 1) : 0; }
 };
 
 struct ConvOp {
@@ -69,9 +72,11 @@ struct ConvOp {
   // split precision (RTP_PREC_MIXED / F16X3): the K loop runs the passes [a_hi x W_hi] [a_lo x W_hi] [a_hi x W_lo]
   bool split_a = false, split_w = false;
   int ncp = 1;              // chunks of ONE pass (nchunk = ncp * passes)
-  int passes() const { return 1 + (split_a ? 1 : 0) + (split_w ? 1 : 0); }
-  int wrap_at() const { return split_w ? (split_a ? 2 * ncp : ncp) : 0; }
-  int last_phys() const { return split_w ? ncp - 1 : (split_a ? 2 * ncp - 1 : ncp - 1); }
+  bool h8 = false;          // the two correction passes run as ONE fp8 chunk per channel group (MX-scaled MFMA, 2x the fp16 rate)
+  int wq_exp = 0;           // h8: fp8(W * 2^wq_exp), fp8(W_lo * 2^(wq_exp + 11))
+  int passes() const { return h8 ? 2 : 1 + (split_a ? 1 : 0) + (split_w ? 1 : 0); }  // in units of one fp16 pass of MFMA time
+  int wrap_at() const { return h8 ? 0 : (split_w ? (split_a ? 2 * ncp : ncp) : 0); }
+  int last_phys() const { return h8 ? ncp - 1 : (split_w ? ncp - 1 : (split_a ? 2 * ncp - 1 : ncp - 1)); }
   int fused = 0;            // 1 / 2: first / second 1x1 of a conv_pw2 step (weights packed for that kernel)
   int fused_chunks = 0;     // middle channels / 128
   size_t w_off = 0, b_off = 0, w_bytes = 0;
@@ -188,6 +193,7 @@ struct rtp_engine {
   unsigned char* prep_tables = nullptr;
   bool gpu_prep_ok = false;
   bool use_graph = true;
+  bool split_fp8 = true;    // RTP_SPLIT_FP8=0: split layers run three fp16 passes everywhere
   bool graph_post = false;  // RTP_GRAPH_POST=1: also capture the per-frame post-processing chains + D2H into the batch graph
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
   std::string split_rules;
@@ -457,10 +463,7 @@ int build_plan(rtp_engine* e) {
   for (auto& c : e->convs) {
     layer_split(e, c, &c.split_w, &c.split_a);
     if (c.first) c.split_a = false;  // the image (u8/256 - 0.5) is exact in fp16: its lo part is zero
-    if (c.split_a) e->tensors[c.in_tensor].split = true;
   }
-  for (size_t pi = e->pools.size(); pi-- > 0;)  // a split pool output needs the lo parts of its input
-    if (e->tensors[e->pools[pi].out_tensor].split) e->tensors[e->pools[pi].in_tensor].split = true;
 
   // steps + pairing + tile configuration
   e->steps.clear();
@@ -539,7 +542,22 @@ int build_plan(rtp_engine* e) {
     }
   }
 
-  for (auto& c : e->convs) {  // K chunks: one pass = ncp chunks of rowb bytes; split layers run 2-3 passes
+  // fp8 compensation where the kernel supports it: ring kernels whose waves own >= 64 bytes of K per chunk
+  for (auto& c : e->convs) {
+    const int ksplit = c.cfg == CFG_128x128 ? 1 : (c.cfg == CFG_64x64 ? 4 : 2);
+    const int gpw = (c.rowb / 32) / ksplit;
+    c.h8 = e->split_fp8 && e->mode == RTP_PREC_MIXED && e->prec == 0 && c.impl == 1 && c.split_a && c.split_w && gpw >= 2 && gpw % 2 == 0;
+    if (c.split_a) { if (c.h8) e->tensors[c.in_tensor].need_q = true; else e->tensors[c.in_tensor].need_lo = true; }
+  }
+  for (auto& s : e->steps)  // both branches of a pair run the same kernel
+    if (s.type == 1 && s.b >= 0 && e->convs[s.a].h8 != e->convs[s.b].h8) {
+      for (int idx : {s.a, s.b}) { ConvOp& c = e->convs[idx]; if (c.h8) { c.h8 = false; e->tensors[c.in_tensor].need_lo = true; } }
+    }
+  for (size_t pi = e->pools.size(); pi-- > 0;) {  // a pool output with lo / q parts needs them in its input
+    if (e->tensors[e->pools[pi].out_tensor].need_lo) e->tensors[e->pools[pi].in_tensor].need_lo = true;
+    if (e->tensors[e->pools[pi].out_tensor].need_q) e->tensors[e->pools[pi].in_tensor].need_q = true;
+  }
+  for (auto& c : e->convs) {  // K chunks: one pass = ncp chunks of rowb bytes; split layers run 2-3 passes (h8: hi chunks + q chunks)
     c.ncp = c.nchunk;
     c.nchunk = c.ncp * c.passes();
   }
@@ -610,6 +628,26 @@ int build_plan(rtp_engine* e) {
 }
 
 // ---- weight packing -------------------------------------------------------------------------
+// float -> OCP e4m3 (round to nearest even, subnormals kept, clamped to +-448): what v_cvt_pk_fp8_f32 does after the clamp
+unsigned char f32_to_e4m3(float x) {
+  const unsigned sign = std::signbit(x) ? 0x80u : 0u;
+  float a = std::fabs(x);
+  if (a != a) return 0x7f;
+  if (a >= 448.f) return (unsigned char)(sign | 0x7e);
+  if (a >= 0.015625f) {  // normal: 2^-6 and up
+    int e;
+    (void)std::frexp(a, &e);                       // a in [2^(e-1), 2^e)
+    const float scaled = std::ldexp(a, -(e - 1));  // [1, 2)
+    int M = (int)std::nearbyint((scaled - 1.f) * 8.f);
+    int E = e - 1 + 7;
+    if (M == 8) { M = 0; ++E; }
+    if (E > 15 || (E == 15 && M == 7)) return (unsigned char)(sign | 0x7e);
+    return (unsigned char)(sign | (unsigned)(E << 3) | (unsigned)M);
+  }
+  const int M = (int)std::nearbyint(std::ldexp(a, 9));  // subnormal: M * 2^-9, M = 8 is the smallest normal
+  return (unsigned char)(sign | (unsigned)(M == 8 ? 8 : M));
+}
+
 template <typename T>
 void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w, const std::vector<float>& b,
                std::vector<unsigned char>* out_w, std::vector<float>* out_b) {
@@ -670,6 +708,17 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
             const float wv = w[((size_t)(n * c.cin + cr) * c.k + r) * c.k + s];
             const T hi = (T)wv;
             const T lo = (T)(wv - (float)hi);
+            if (c.h8) {  // [hi chunks: fp16 W_hi] [q chunks: per 64-channel group 64 B fp8(W_hi * 2^wq) | 64 B fp8(W_lo * 2^(wq+11))]
+              const size_t tile0 = (size_t)(r * c.nchunk + chunk) * c.k + s;
+              pw[(tile0 * c.CoutP + n) * per_chunk + kpos(n, kk)] = hi;
+              const size_t tileq = (size_t)(r * c.nchunk + c.ncp + chunk) * c.k + s;
+              unsigned char* qrow = out_w->data() + (tileq * c.CoutP + n) * c.rowb;
+              const int g = kk / 64, pos = kk % 64;
+              auto qpos = [&](int byte) { return ((byte / 16) ^ conv_ring_swz(c.rowb, n)) * 16 + byte % 16; };
+              qrow[qpos(g * 128 + pos)] = f32_to_e4m3(std::ldexp((float)hi, c.wq_exp));
+              qrow[qpos(g * 128 + 64 + pos)] = f32_to_e4m3(std::ldexp(wv - (float)hi, c.wq_exp + 11));
+              continue;
+            }
             // passes of a split layer are further chunks of the K loop: [a_hi x W_hi] [a_lo x W_hi] [a_hi x W_lo]
             int vbase = 0;
             for (int pass = 0; pass < 3; ++pass) {
@@ -684,6 +733,18 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
   }
   out_b->assign(c.CoutP, 0.f);
   for (int n = 0; n < c.cout; ++n) (*out_b)[n] = b[n];
+}
+
+// h8 layers: one power-of-two scale for the fp8 weight copies, shared by the two branches of a paired launch
+void compute_wq_exp(rtp_engine* e) {
+  for (auto& s : e->steps) {
+    if (s.type != 1 || !e->convs[s.a].h8) continue;
+    float mx = 0.f;
+    for (int idx : {s.a, s.b}) if (idx >= 0) for (float v : e->w_ref[idx]) mx = std::max(mx, std::fabs(v));
+    int ex = mx > 0.f ? (int)std::floor(std::log2(448.0 / mx)) : 0;
+    ex = std::max(-20, std::min(ex, 40));
+    for (int idx : {s.a, s.b}) if (idx >= 0) e->convs[idx].wq_exp = ex;
+  }
 }
 
 int upload_conv_weights(rtp_engine* e, int i) {
@@ -710,6 +771,7 @@ void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProbl
     pr->dst[d].cstride = t.stride();
     pr->dst[d].coff = c.dsts[d].second;
     pr->dst[d].lo_off = t.lo_off();
+    pr->dst[d].q_off = t.q_off();
   }
   if (c.to_lowres) {
     pr->out_nchw = cx.lowres;
@@ -732,6 +794,14 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
   P.nchunk = A.nchunk;
   P.wrap_at = A.wrap_at();
   P.last_phys = A.last_phys();
+  {
+    const Tensor& tin = e->tensors[A.in_tensor];
+    const int qb = tin.q_off() * e->elem;  // byte offset of the input's q block inside a pixel
+    P.q_from = A.h8 ? A.ncp : 0;
+    P.jump_delta = A.h8 ? qb - (A.ncp - 1) * A.rowb : 0;
+    P.row_back = A.h8 ? qb + (A.ncp - 1) * A.rowb : A.last_phys() * A.rowb;
+    P.wq_exp = A.wq_exp;
+  }
   P.CoutP = A.CoutP;
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
@@ -831,7 +901,7 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bo
       const Tensor& ti = e->tensors[p.in_tensor];
       const Tensor& to = e->tensors[p.out_tensor];
       HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.stride(), cx.arena + to.offset, geom_n(to.level), to.stride(),
-                               round_up(p.C, 16 / e->elem), ti.lo_off(), to.lo_off(), cx.stream));
+                               round_up(p.C, 16 / e->elem), ti.lo_off(), to.lo_off(), ti.q_off(), to.q_off(), cx.stream));
     }
   }
   return RTP_OK;
@@ -1262,6 +1332,8 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     e->use_graph = cfg->exec_mode == RTP_EXEC_GRAPH;
     if (eg && !strcmp(eg, "eager")) e->use_graph = false;
     if (eg && !strcmp(eg, "graph")) e->use_graph = true;
+    const char* f8 = getenv("RTP_SPLIT_FP8");
+    e->split_fp8 = !(f8 && f8[0] == '0');
     const char* gp = getenv("RTP_GRAPH_POST");
     e->graph_post = gp && gp[0] == '1';
   }
@@ -1317,6 +1389,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     s = hipMalloc((void**)&e->dchmap, 4096 * sizeof(int));
     if (s != hipSuccess) return bail(fail(e, RTP_ENOMEM, "hipMalloc failed"));
   }
+  compute_wq_exp(e);
   for (size_t i = 0; i < e->convs.size(); ++i)
     if ((rc = upload_conv_weights(e, (int)i))) return bail(rc);
   e->ctx.resize((cfg->frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0));  // batches in flight (+1 being filled)
@@ -1687,7 +1760,7 @@ int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int sh
   float* dtmp = nullptr;
   HIPCHK(e, hipMalloc((void**)&dtmp, n * sizeof(float)));
   hipError_t s = hipMemcpy(e->dchmap, t.chmap.data(), t.C * sizeof(int), hipMemcpyHostToDevice);
-  if (s == hipSuccess) s = launch_export(e->prec, cx.arena + t.offset, g, t.stride(), e->dchmap, t.C, t.lo_off(), dtmp, cx.stream);
+  if (s == hipSuccess) s = launch_export(e->prec, cx.arena + t.offset, g, t.stride(), e->dchmap, t.C, t.lo_off(), t.q_off(), dtmp, cx.stream);
   if (s == hipSuccess) s = hipStreamSynchronize(cx.stream);
   if (s == hipSuccess) s = hipMemcpy(out, dtmp, n * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(dtmp);
@@ -1719,6 +1792,13 @@ int rtp_set_conv_weights(rtp_engine* e, int i, const float* w, const float* b) {
   e->w_ref[i].assign(w, w + e->w_ref[i].size());
   e->b_ref[i].assign(b, b + e->b_ref[i].size());
   HIPCHK(e, hipDeviceSynchronize());
+  if (e->convs[i].h8) {  // the fp8 scale is shared with the other branch of the launch: re-pack both when it moves
+    std::vector<int> old(e->convs.size());
+    for (size_t j = 0; j < e->convs.size(); ++j) old[j] = e->convs[j].wq_exp;
+    compute_wq_exp(e);
+    for (size_t j = 0; j < e->convs.size(); ++j)
+      if ((int)j != i && e->convs[j].wq_exp != old[j] && (rc = upload_conv_weights(e, (int)j))) return rc;
+  }
   return upload_conv_weights(e, i);
 }
 int rtp_save_caffemodel(const rtp_engine* e, const char* path) {
@@ -1870,6 +1950,8 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   {
     const char* sr = getenv("RTP_SPLIT_LAYERS");
     e->split_rules = sr ? sr : (cfg->split_layers ? cfg->split_layers : kDefaultSplit);
+    const char* f8 = getenv("RTP_SPLIT_FP8");
+    e->split_fp8 = !(f8 && f8[0] == '0');
   }
   e->N = cfg->num_scales;
   e->B = cfg->batch_frames < 1 ? 1 : cfg->batch_frames;
@@ -1921,7 +2003,7 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
       o << "step conv " << A.name;
       if (s.b >= 0) o << " + " << e->convs[s.b].name;
       o << " k " << A.k << " cin_p " << A.Cin_p << " cout " << A.cout << " coutp " << A.CoutP << " relu " << A.relu << " tile " << ci.BM << "x" << ci.BN
-        << " rowb " << A.rowb << " passes " << A.passes() << (A.split_a ? "a" : "") << (A.split_w ? "w" : "") << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->NI * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
+        << " rowb " << A.rowb << " passes " << A.passes() << (A.h8 ? "q" : "") << (!A.h8 && A.split_a ? "a" : "") << (!A.h8 && A.split_w ? "w" : "") << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->NI * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";
       for (int idx : {s.a, s.b}) if (idx >= 0) {
         const ConvOp& c = e->convs[idx];
         const double gf = 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9;
@@ -1988,6 +2070,13 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
   return RTP_OK;
 }
 
+// Host float -> OCP e4m3 conversion used for the fp8 weight copies (tests compare it with torch.float8_e4m3fn).
+int rtp_debug_f32_to_e4m3(const float* in, unsigned char* out, int n) {
+  if (!in || !out || n < 0) return RTP_EINVAL;
+  for (int i = 0; i < n; ++i) out[i] = f32_to_e4m3(in[i]);
+  return RTP_OK;
+}
+
 // Per-pass-count breakdown of rtp_kernel_timing's totals: ms[p], launches[p] for p = 1..3 MFMA passes (index 0 unused).
 int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches[4]) {
   if (!e || !ms || !launches) return RTP_EINVAL;
@@ -2019,7 +2108,7 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int ca
         const Tensor& ti = e->tensors[p.in_tensor];
         const Tensor& to = e->tensors[p.out_tensor];
         HIPCHK(e, launch_maxpool(e->prec, cx.arena + ti.offset, geom_n(ti.level), ti.stride(), cx.arena + to.offset, geom_n(to.level), to.stride(),
-                                 round_up(p.C, 16 / e->elem), ti.lo_off(), to.lo_off(), cx.stream));
+                                 round_up(p.C, 16 / e->elem), ti.lo_off(), to.lo_off(), ti.q_off(), to.q_off(), cx.stream));
       }
       return RTP_OK;
     };

@@ -23,6 +23,8 @@ struct ConvDst {
   int cstride;  // channels per pixel of the destination tensor (2*Cp when it carries a lo block)
   int coff;     // first channel this conv writes
   int lo_off;   // 0, or the channel offset of the tensor's lo block: channel c also gets lo = T(v - float(T(v))) at lo_off + c
+  int q_off;    // 0, or the ELEMENT offset of the tensor's q block (fp8 error-compensation operands): per 64-channel group g,
+                // bytes [128g, 128g+64) = fp8(lo * 2^12), bytes [128g+64, 128g+128) = fp8(T(v) * 2^2)   (e4m3, clamped to +-448)
 };
 
 struct ConvProblem {
@@ -46,6 +48,14 @@ struct ConvParams {
                    // packed in that order); the ACTIVATION chunk of virtual chunk v is v, or v - wrap_at from wrap_at on
   int wrap_at;     // 0 = no wrap (the chunks are contiguous in the input tensor)
   int last_phys;   // physical chunk index of the last virtual chunk (nchunk-1 without a wrap)
+  // fp8-compensated split layers (ring kernels): virtual chunks [q_from, nchunk) are q chunks — the same channel groups once
+  // more, as fp8 pairs (a_lo8 x W8, a8 x W_lo8) multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 at twice the fp16 rate
+  int q_from;      // 0 = none
+  int wq_exp;      // the weights' q chunks hold fp8(W * 2^wq_exp) and fp8(W_lo * 2^(wq_exp + 11)); one exponent for both branches
+                   // of a paired launch (a per-problem field read through prob[blockIdx-dependent] made hipcc keep the DMA base
+                   // pointer in VGPRs)
+  int jump_delta;  // bytes from the last hi chunk to the first q chunk of the input tensor (instead of + CHB)
+  int row_back;    // byte offset of a filter row's last virtual chunk relative to its first (ring kernels)
   int CoutP;       // Cout rounded up to a multiple of BN
   int tiles_per_img;
   int nimg;    // images (scales) in the batch
@@ -109,11 +119,13 @@ hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, 
 // 2x2 stride-2 MAX pooling between two halo'd NHWC tensors (pooling_layer.cpp:140-180).
 // lo_i / lo_o: 0, or the channel offset of the lo block of a split-precision tensor — the pooled element keeps ITS lo
 // part (the maximum of hi + lo, not two independent maxima).
-hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o,
+// q_i / q_o: 0, or the element offset of the q block (fp8 compensation operands, ConvDst::q_off) — copied from the selected element.
+hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o, int q_i, int q_o,
                           hipStream_t stream);
 // halo'd NHWC (T) -> planar fp32 [N][C][H][W] (debug tap; channel map: out c reads in chmap[c]).
 // lo_off != 0: the tensor carries a lo block, the exported value is hi + lo.
-hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, int lo_off, float* out,
+// q_off != 0 (and no lo block): the exported value is hi + fp8 lo part / 2^12.
+hipError_t launch_export(int prec, const void* in, Geom g, int Cp, const int* chmap_dev, int C, int lo_off, int q_off, float* out,
                          hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------

@@ -263,6 +263,8 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
 /* The same totals split by the number of MFMA passes of the launch (1 = plain fp16 layer, 3 = split-precision layer);
  * index 0 is unused. */
 int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches[4]);
+/* Host float -> OCP e4m3 (round to nearest even, clamped to +-448): how the fp8 weight copies of split layers are made. */
+int rtp_debug_f32_to_e4m3(const float* in, unsigned char* out, int n);
 
 /* Survivors of the PAF test (temp.size(), rtpose.cpp:950) and accepted connections
  * (connection_k.size(), :980) per limb for the last synchronous frame; arrays of num_limbs ints. */

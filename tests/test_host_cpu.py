@@ -72,7 +72,11 @@ def test_plan_coco_flops_and_pairing():
     assert lines[0] == "model 0 parts 18 max_peaks 64 heat_channels 57"
     gf = {l.split()[0]: float(l.split()[1]) for l in lines if l.startswith(("conv_gflop", "mfma_gflop"))}
     assert gf["conv_gflop"] == pytest.approx(484.634, abs=1e-3)
-    assert gf["mfma_gflop"] == pytest.approx(1139.45, abs=1e-2)   # default precision (mixed): split layers run three MFMA passes
+    # default precision (mixed): split 3x3 / 7x7 layers cost one fp16 pass + one fp8 compensation chunk per channel group (= 2 pass
+    # times), split 1x1 layers three fp16 passes
+    assert 810 < gf["mfma_gflop"] < 900      # (814.8 when every split k x k layer's tile supports the fp8 chunks, e.g. at batch_frames 2)
+    b2 = _plan_lines(batch_frames=2)
+    assert float([l for l in b2 if l.startswith("mfma_gflop")][0].split()[1]) == pytest.approx(814.765, abs=1e-2)
     fp16 = _plan_lines(precision=0)
     assert float([l for l in fp16 if l.startswith("mfma_gflop")][0].split()[1]) == pytest.approx(484.634, abs=1e-3)
     convs = [l for l in lines if l.startswith("step conv")]
@@ -384,6 +388,8 @@ def test_split_precision_plan_and_rule_syntax():
     assert "passes 1 " not in allx.replace("passes 1 impl reg wgs 3784", "")   # conv1_1: image exact in fp16, weights split only
     s = r.plan_summary(r.Config(precision=r.PREC_MIXED, split_layers="conv4_4:w,*_stage6_L:a,@1x1"))
     lines = {ln.split()[2]: ln for ln in s.splitlines() if ln.startswith(("step conv", "step pw2"))}
-    assert " passes 2w " in lines["conv4_4_CPM"] and " passes 2a " in lines["Mconv2_stage6_L1"]
+    assert " passes 2w " in lines["conv4_4_CPM"] and " passes 2a " in lines["Mconv2_stage6_L1"]   # partial splits stay fp16 passes
+    dflt = {ln.split()[2]: ln for ln in r.plan_summary(r.Config(precision=r.PREC_MIXED)).splitlines() if ln.startswith(("step conv", "step pw2"))}
+    assert " passes 2q " in dflt["conv3_2"] and " passes 2q " in dflt["Mconv3_stage6_L1"] and " passes 1 " in dflt["Mconv3_stage3_L1"]
     assert " passes 1 " in lines["conv3_1"]
     assert " passes 3aw/3aw " in lines["Mconv6_stage6_L1"]   # the fused 1x1 pair: passes of the first / second layer
