@@ -1,6 +1,6 @@
 // aux_kernels.hip — the HBM-bound glue of the conv stack: input packing, 2x2 max pooling and
 // the debug export.  All are pure streaming kernels: 16-byte vector accesses, one pass.
-#include "kernels.h"
+#include "conv_common.h"
 
 namespace rtp {
 
@@ -60,7 +60,7 @@ __device__ __forceinline__ float e4m3_to_float(unsigned b) {
 }
 
 // ---- 2x2 / stride 2 MAX pooling (pooling_layer.cpp:140-180; resolutions are even) ----------
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, Geom gi, int Cpi, T* __restrict__ out,
                                                        Geom go, int Cpo, int C, int lo_i, int lo_o, int q_i, int q_o) {
   constexpr int VEC = 16 / sizeof(T);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
       __builtin_memcpy(h[q], &v, 16);
     }
     T* op = out + (((long)n * go.Hp + y + go.halo) * go.Wp + x + go.halo) * Cpo + c;
-    if (!lo_i && !q_i) {
+    if constexpr (!SPLIT) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         T m = h[0][i];
@@ -153,14 +153,84 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
   }
 }
 
+// 2x2 max pooling of a tensor that carries fp8 compensation operands (q block, ConvDst::q_off): 8 channels per thread.
+// The value of an element is hi + lo8 / 2^12; the first maximum in (0,0),(0,1),(1,0),(1,1) order keeps its parts (ties on hi
+// are broken by lo8, compared through an order-preserving integer key).  hi8 = fp8(hi * 2^2) is a function of hi alone, so
+// it is recomputed for the selected element with the conversion the conv epilogue uses instead of being read (a quarter
+// less read traffic).  Packed integer state: the byte-array version of this kernel needed 234 VGPRs.
+__global__ __launch_bounds__(256) void maxpool_q_kernel(const _Float16* __restrict__ in, Geom gi, int Cpi, _Float16* __restrict__ out,
+                                                        Geom go, int Cpo, int C, int q_i, int q_o) {
+  const int cv = C / 8;
+  const long total = (long)go.N * go.H * go.W * cv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * 8;
+    long p = idx / cv;
+    const int x = (int)(p % go.W);
+    p /= go.W;
+    const int y = (int)(p % go.H);
+    const int n = (int)(p / go.H);
+    const _Float16* ip = in + (((long)n * gi.Hp + 2 * y + gi.halo) * gi.Wp + 2 * x + gi.halo) * Cpi + c;
+    const long offs[4] = {0, Cpi, (long)gi.Wp * Cpi, (long)gi.Wp * Cpi + Cpi};
+    half8_t h[4];
+    uint2 l8[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = *(const uint4*)(ip + offs[q]);
+      __builtin_memcpy(&h[q], &v, 16);
+      l8[q] = *(const uint2*)((const unsigned char*)(ip - c + offs[q] + q_i) + (c >> 6) * 128 + (c & 63));
+    }
+    half8_t oh;
+    unsigned ol8[2] = {0u, 0u};
+    float ohf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      auto lo_byte = [&](int q) { return ((i < 4 ? l8[q].x : l8[q].y) >> (8 * (i & 3))) & 0xffu; };
+      auto key = [](unsigned b) { return (b & 0x80u) ? 0x80 - (int)(b & 0x7fu) : 0x80 + (int)b; };  // monotonic in the e4m3 value, -0 == +0
+      _Float16 mh = h[0][i];
+      unsigned mb = lo_byte(0);
+      int mk = key(mb);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const _Float16 hq = h[q][i];
+        const unsigned b = lo_byte(q);
+        const int k = key(b);
+        const bool gt = hq > mh || (hq == mh && k > mk);
+        mh = gt ? hq : mh;
+        mb = gt ? b : mb;
+        mk = gt ? k : mk;
+      }
+      oh[i] = mh;
+      ohf[i] = (float)mh * (float)(1 << Q_HI_EXP);
+      ol8[i >> 2] |= mb << (8 * (i & 3));
+    }
+    _Float16* op = out + (((long)n * go.Hp + y + go.halo) * go.Wp + x + go.halo) * Cpo + c;
+    uint4 r;
+    __builtin_memcpy(&r, &oh, 16);
+    *(uint4*)op = r;
+    if (q_o) {
+      unsigned char* qp = (unsigned char*)(op - c + q_o) + (c >> 6) * 128 + (c & 63);
+      uint2 a, b;
+      a.x = ol8[0]; a.y = ol8[1];
+      b.x = pack4_fp8(ohf[0], ohf[1], ohf[2], ohf[3]); b.y = pack4_fp8(ohf[4], ohf[5], ohf[6], ohf[7]);
+      *(uint2*)qp = a;
+      *(uint2*)(qp + 64) = b;
+    }
+  }
+}
+
 hipError_t launch_maxpool(int prec, const void* in, Geom gi, int Cpi, void* out, Geom go, int Cpo, int C, int lo_i, int lo_o, int q_i, int q_o,
                           hipStream_t stream) {
   const int vec = prec == 0 ? 8 : 4;
   const long total = (long)go.N * go.H * go.W * (C / vec);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (prec == 0) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, lo_i, lo_o, q_i, q_o);
-  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C, lo_i, lo_o, 0, 0);
+  if (prec == 0 && q_i && !lo_i)
+    hipLaunchKernelGGL(maxpool_q_kernel, dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, q_i, q_o);
+  else if (prec == 0 && (lo_i || q_i))
+    hipLaunchKernelGGL((maxpool_kernel<_Float16, true>), dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, lo_i, lo_o, q_i, q_o);
+  else if (prec == 0)
+    hipLaunchKernelGGL((maxpool_kernel<_Float16, false>), dim3(blocks), dim3(256), 0, stream, (const _Float16*)in, gi, Cpi, (_Float16*)out, go, Cpo, C, 0, 0, 0, 0);
+  else hipLaunchKernelGGL((maxpool_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, (const float*)in, gi, Cpi, (float*)out, go, Cpo, C, 0, 0, 0, 0);
   return hipGetLastError();
 }
 

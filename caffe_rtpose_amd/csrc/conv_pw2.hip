@@ -28,9 +28,35 @@ constexpr int PW_ROW = 256;           // 128 fp16 channels
 constexpr int PW_STR = PW_ROW + 16;   // padded LDS row: the 16 rows of a ds_read_b128 lane group hit 16 distinct bank quads
 constexpr int PW_X = PW_BM * PW_STR;  // one 64-row operand image (X_hi, X_lo, H_hi, H_lo)
 constexpr int PW_W = 128 * PW_STR;    // one weight block (W1 chunk: 128 rows; W2 slice: the first 64 rows)
-constexpr int PW_LDS = 4 * PW_X + PW_W;  // 104,448 B
+constexpr int PW_MAXMID = 512;         // middle channels whose bias is staged in LDS
+constexpr int PW_LDS = 4 * PW_X + PW_W + PW_MAXMID * 4;  // 106,496 B
 static_assert(PW_LDS >= 64 * 64 * 4, "epilogue scratch fits");
 }  // namespace
+
+// weight blocks in flight live in SSA vectors (an array of uint4 ends up in scratch: the unrolled indices are not constant
+// yet when allocas are promoted)
+typedef unsigned int u32x32 __attribute__((ext_vector_type(32)));
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+template <typename V>
+__device__ __forceinline__ void pw_fetch(V& reg, const unsigned char* src, int tid) {
+  constexpr int NV = sizeof(V) / 16;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const uint4 t = *(const uint4*)(src + (size_t)(tid + i * 256) * 16);
+    reg[4 * i] = t.x; reg[4 * i + 1] = t.y; reg[4 * i + 2] = t.z; reg[4 * i + 3] = t.w;
+  }
+}
+template <typename V>
+__device__ __forceinline__ void pw_stash(const V& reg, unsigned char* sW, int tid) {
+  constexpr int NV = sizeof(V) / 16;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256;
+    uint4 t;
+    t.x = reg[4 * i]; t.y = reg[4 * i + 1]; t.z = reg[4 * i + 2]; t.w = reg[4 * i + 3];
+    *(uint4*)(sW + (v >> 4) * PW_STR + (v & 15) * 16) = t;
+  }
+}
 
 __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -39,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
   unsigned char* sHh = smem + 2 * PW_X;
   unsigned char* sHl = smem + 3 * PW_X;
   unsigned char* sW = smem + 4 * PW_X;
+  float* sB1 = (float*)(smem + 4 * PW_X + PW_W);
 
   const ConvParams& P = Q.P2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,38 +78,46 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
   const ConvProblem& pr = P.prob[prob];
   const long pix0 = (long)img * P.img_pix + (long)P.halo * P.Wp + m0;  // first pixel of the tile (flat padded index)
   const int Mtot = P.H * P.Wp;
+  // diagnostics (RTP_PW2_PROBE): 100 MHz wall-clock stamps of workgroup 0 at the phase boundaries
+  int stamp_i = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (P.clkprobe && blockIdx.x == 0 && tid == 0 && stamp_i < 31) P.clkprobe[1 + stamp_i++] = wall_clock64();
+  };
+  stamp();
 
-  // ---- X tile: 64 rows x 256 B (+ lo block) -> LDS ---------------------------------------------------------
+  // requests in the order they are needed: middle bias, X tile, weight blocks (vmcnt waits are in order)
+  // two-entry kernarg arrays are selected, not indexed: a dynamic index turns into a dependent global load of the pointer
+  const float* b1p = prob ? Q.b1[1] : Q.b1[0];
+  const int nmid = Q.c1_chunks * 128;
+  const float b_a = tid < nmid ? b1p[tid] : 0.f;
+  const float b_b = tid + 256 < nmid ? b1p[tid + 256] : 0.f;
+  // ---- X tile: 64 rows x 256 B (+ lo block): all requests first (4 + 4 uint4 per thread), LDS stores after the weight requests
+  u32x16 r_xh, r_xl;
   {
-    const _Float16* xin = (const _Float16*)Q.x_in[prob] + pix0 * Q.x_cstride;
-    for (int v = tid; v < PW_BM * 16; v += 256) {
-      const int row = v >> 4, seg = v & 15;
-      const uint4 h = *(const uint4*)((const unsigned char*)(xin + (long)row * Q.x_cstride) + seg * 16);
-      *(uint4*)(sXh + row * PW_STR + seg * 16) = h;
+    const _Float16* xin = (const _Float16*)(prob ? Q.x_in[1] : Q.x_in[0]) + pix0 * Q.x_cstride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + i * 256, row = v >> 4, seg = v & 15;
+      const unsigned char* src = (const unsigned char*)(xin + (long)row * Q.x_cstride) + seg * 16;
+      const uint4 h = *(const uint4*)src;
+      r_xh[4 * i] = h.x; r_xh[4 * i + 1] = h.y; r_xh[4 * i + 2] = h.z; r_xh[4 * i + 3] = h.w;
       if (Q.x_lo_off) {
-        const uint4 l = *(const uint4*)((const unsigned char*)(xin + (long)row * Q.x_cstride + Q.x_lo_off) + seg * 16);
-        *(uint4*)(sXl + row * PW_STR + seg * 16) = l;
+        const uint4 l = *(const uint4*)(src + (size_t)Q.x_lo_off * 2);
+        r_xl[4 * i] = l.x; r_xl[4 * i + 1] = l.y; r_xl[4 * i + 2] = l.z; r_xl[4 * i + 3] = l.w;
       }
     }
   }
-  // weight block fetch: rows x 256 B contiguous in global -> registers (8 uint4 per thread for 128 rows)
-  uint4 wreg[8];
-  auto fetch = [&](const unsigned char* src, int rows) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int v = tid + i * 256;
-      if (v < rows * 16) wreg[i] = *(const uint4*)(src + (size_t)v * 16);
-    }
-  };
-  auto stash = [&](int rows) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int v = tid + i * 256;
-      if (v < rows * 16) *(uint4*)(sW + (v >> 4) * PW_STR + (v & 15) * 16) = wreg[i];
-    }
-  };
+  // Weight blocks travel global -> registers -> LDS.  Every block of the current 128-channel chunk of the middle layer
+  // has its OWN registers (W1 hi / lo: 8 uint4 each, W2 hi / lo: 4 each = 96 VGPRs; one wave per SIMD, registers are free)
+  // and is requested a whole chunk ahead: at kernel start, then again as soon as its registers have been stashed.  The L2 /
+  // HBM latency (2.5-3 us per block when waited for, RTP_PW2_PROBE) is paid once, under the X tile load, instead of per block.
+  // Barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would wait for vmcnt(0), i.e. for every
+  // prefetch in flight.
+  u32x32 r_w1h, r_w1l;
+  u32x16 r_w2h, r_w2l;
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // one GEMM pass over K = 128 of NT 32-row tiles: acc[i] += A(rows a_row0 + i*32 + lrow of a_img) x B(rows b_row0 + lrow of sW)
-  auto gemm = [&](const unsigned char* a_img, int a_row0, auto ntm_tag, int b_row0, floatx16* acc) {
+  auto gemm = [&](const unsigned char* a_img, int a_row0, auto ntm_tag, int b_row0, floatx16* acc) __attribute__((always_inline)) {
     constexpr int NT = decltype(ntm_tag)::value;
     const unsigned char* pb = sW + (b_row0 + lrow) * PW_STR + lhalf * 16;
     const unsigned char* pa = a_img + (a_row0 + lrow) * PW_STR + lhalf * 16;
@@ -100,39 +135,61 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
   const std::integral_constant<int, 1> one{};
 
   const int w1_parts = Q.split_w1 ? 2 : 1, w2_parts = Q.split_w2 ? 2 : 1;
-  const unsigned char* w1 = (const unsigned char*)Q.w1[prob];
-  const unsigned char* w2 = (const unsigned char*)pr.w;
+  const unsigned char* w1 = (const unsigned char*)(prob ? Q.w1[1] : Q.w1[0]);
+  const unsigned char* w2 = (const unsigned char*)(prob ? P.prob[1].w : P.prob[0].w);
   const size_t W1_BLK = 128 * PW_ROW, W2_BLK = 64 * PW_ROW;
+  auto w1_blk = [&](int c, int part) { return w1 + ((size_t)c * w1_parts + part) * W1_BLK; };
+  auto w2_blk = [&](int c, int part) { return w2 + ((size_t)c * w2_parts + part) * W2_BLK; };
 
   floatx16 acc2;  // wave (w>>1, w&1): rows (w>>1)*32.., output channels (w&1)*32..
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc2[q] = 0.f;
 
-  fetch(w1, 128);  // W1_hi of chunk 0
+  pw_fetch(r_w1h, w1_blk(0, 0), tid);
+  if (Q.split_w1) pw_fetch(r_w1l, w1_blk(0, 1), tid);
+  pw_fetch(r_w2h, w2_blk(0, 0), tid);
+  if (Q.split_w2) pw_fetch(r_w2l, w2_blk(0, 1), tid);
+  sB1[tid] = b_a;
+  sB1[tid + 256] = b_b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + i * 256, row = v >> 4, seg = v & 15;
+    uint4 t;
+    t.x = r_xh[4 * i]; t.y = r_xh[4 * i + 1]; t.z = r_xh[4 * i + 2]; t.w = r_xh[4 * i + 3];
+    *(uint4*)(sXh + row * PW_STR + seg * 16) = t;
+    if (Q.x_lo_off) {
+      t.x = r_xl[4 * i]; t.y = r_xl[4 * i + 1]; t.z = r_xl[4 * i + 2]; t.w = r_xl[4 * i + 3];
+      *(uint4*)(sXl + row * PW_STR + seg * 16) = t;
+    }
+  }
+  stamp();
   for (int c = 0; c < Q.c1_chunks; ++c) {
+    const bool more = c + 1 < Q.c1_chunks;
     floatx16 acc1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc1[i][q] = 0.f;
     // ---- GEMM1: H_c = X x W1[c]^T ----
-    __syncthreads();              // X tile stored (c == 0) / previous readers of sW and sH are done
-    stash(128);
-    if (Q.split_w1) fetch(w1 + ((size_t)c * w1_parts + 1) * W1_BLK, 128);
-    else fetch(w2 + (size_t)c * w2_parts * W2_BLK, 64);
-    __syncthreads();
+    lds_barrier();                // X tile stored (c == 0) / previous readers of sW and sH are done
+    pw_stash(r_w1h, sW, tid);
+    if (more) pw_fetch(r_w1h, w1_blk(c + 1, 0), tid);
+    lds_barrier();
+    stamp();
     gemm(sXh, 0, two, wave * 32, acc1);
     if (Q.x_lo_off) gemm(sXl, 0, two, wave * 32, acc1);
+    stamp();
     if (Q.split_w1) {
-      __syncthreads();
-      stash(128);
-      fetch(w2 + (size_t)c * w2_parts * W2_BLK, 64);
-      __syncthreads();
+      lds_barrier();
+      pw_stash(r_w1l, sW, tid);
+      if (more) pw_fetch(r_w1l, w1_blk(c + 1, 1), tid);
+      lds_barrier();
       gemm(sXh, 0, two, wave * 32, acc1);
+      stamp();
     }
     // ---- + b1, ReLU, H -> LDS (fp16 hi / lo) ----
     {
-      const float bias = Q.b1[prob][c * 128 + wave * 32 + lrow];
+      const float bias = sB1[c * 128 + wave * 32 + lrow];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -145,13 +202,19 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
           if (Q.h_lo) *(_Float16*)(sHl + row * PW_STR + (wave * 32 + lrow) * 2) = (_Float16)(v - (float)hi);
         }
     }
-    __syncthreads();              // H complete; every wave is past its reads of sW
-    stash(64);                    // W2_hi[:, c]
-    if (Q.split_w2) fetch(w2 + ((size_t)c * w2_parts + 1) * W2_BLK, 64);
-    else if (c + 1 < Q.c1_chunks) fetch(w1 + (size_t)(c + 1) * w1_parts * W1_BLK, 128);
-    // the middle layer's own blob (interior pixels only; the halo stays zero)
-    if (Q.mid[prob].base) {
-      const ConvDst& md = Q.mid[prob];
+    stamp();
+    lds_barrier();                // H complete; every wave is past its reads of sW
+    pw_stash(r_w2h, sW, tid);                 // W2_hi[:, c]
+    if (more) pw_fetch(r_w2h, w2_blk(c + 1, 0), tid);
+    lds_barrier();
+    stamp();
+    // ---- GEMM2: Y += H_c x W2[:, c]^T ----
+    gemm(sHh, (wave >> 1) * 32, one, (wave & 1) * 32, &acc2);
+    if (Q.h_lo) gemm(sHl, (wave >> 1) * 32, one, (wave & 1) * 32, &acc2);
+    stamp();
+    // the middle layer's own blob (interior pixels only; the halo stays zero): plain stores, nobody waits for them
+    const ConvDst& md = prob ? Q.mid[1] : Q.mid[0];
+    if (md.base) {
       for (int v = tid; v < PW_BM * 16; v += 256) {
         const int row = v >> 4, seg = v & 15;
         const int m = m0 + row;
@@ -162,21 +225,22 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
         if (md.lo_off) *(uint4*)(dp + md.lo_off) = *(const uint4*)(sHl + row * PW_STR + seg * 16);
       }
     }
-    __syncthreads();
-    // ---- GEMM2: Y += H_c x W2[:, c]^T ----
-    gemm(sHh, (wave >> 1) * 32, one, (wave & 1) * 32, &acc2);
-    if (Q.h_lo) gemm(sHl, (wave >> 1) * 32, one, (wave & 1) * 32, &acc2);
+    stamp();
     if (Q.split_w2) {
-      __syncthreads();
-      stash(64);
-      if (c + 1 < Q.c1_chunks) fetch(w1 + (size_t)(c + 1) * w1_parts * W1_BLK, 128);
-      __syncthreads();
+      lds_barrier();
+      pw_stash(r_w2l, sW, tid);
+      if (more) pw_fetch(r_w2l, w2_blk(c + 1, 1), tid);
+      lds_barrier();
       gemm(sHh, (wave >> 1) * 32, one, (wave & 1) * 32, &acc2);
+      stamp();
     }
   }
   __syncthreads();  // LDS is reused by the epilogue
+  stamp();
   floatx16 acc[1][1] = {{acc2}};
   conv_epilogue<_Float16, 64, 64, 2, 2, 1, 1, 1>(P, pr, acc, smem, 0, wave, (wave >> 1) * 32, (wave & 1) * 32, lane, img, m0, 0);
+  stamp();
+  if (P.clkprobe && blockIdx.x == 0 && tid == 0) P.clkprobe[0] = stamp_i;
 }
 
 hipError_t launch_conv_pw2(const Pw2Params& Q, int nprob, int nimg, hipStream_t stream) {

@@ -656,6 +656,8 @@ static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int npr
     case CFG_128x128: return ring_launch_one<T, 128, 128, 2, 2, 1, KS, 128, 4>(P, nprob, N, stream);
     case CFG_64x128: return ring_launch_one<T, 64, 128, 1, 2, 2, KS, 128, 4>(P, nprob, N, stream);
     case CFG_64x64:
+      // fp8-compensated layers need >= 64 bytes of K per wave and chunk: waves 2 (M) x 1 (N) x 2 (K) instead of 4-way K split
+      if (P.q_from > 0) return ring_launch_one<T, 64, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);
       // 56 KiB of LDS and <= 128 registers: two workgroups (of different frames) share a CU
       return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 4, 2>(P, nprob, N, stream);
     case CFG_128x64: return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);

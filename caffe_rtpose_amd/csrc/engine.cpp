@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -69,6 +70,7 @@ struct ConvOp {
   int level = 0;
   int Cin_p = 0, rowb = 128, nchunk = 1, CoutP = 0, cfg = 0;
   int impl = 0;             // 0 = register-staged kernel (conv_igemm.hip), 1 = LDS-DMA ring (conv_ring.hip)
+  bool direct_first = false;  // conv1_1 straight from the NCHW input (conv_first.hip): no im2col tensor, no pack step
   // split precision (RTP_PREC_MIXED / F16X3): the K loop runs the passes [a_hi x W_hi] [a_lo x W_hi] [a_hi x W_lo]
   bool split_a = false, split_w = false;
   int ncp = 1;              // chunks of ONE pass (nchunk = ncp * passes)
@@ -83,7 +85,7 @@ struct ConvOp {
 };
 
 struct Step {
-  int type;  // 0 pack, 1 conv, 2 pool, 3 two chained 1x1 convolutions in one launch (conv_pw2.hip)
+  int type;  // 0 pack, 1 conv, 2 pool, 3 two chained 1x1 convolutions in one launch (conv_pw2.hip), 4 input convolution from the NCHW image (conv_first.hip)
   int a = -1, b = -1;    // conv (a) [+ the other branch's conv (b)]; pool index for type 2
   int a2 = -1, b2 = -1;  // type 3: the second 1x1 of each branch
 };
@@ -544,7 +546,8 @@ int build_plan(rtp_engine* e) {
 
   // fp8 compensation where the kernel supports it: ring kernels whose waves own >= 64 bytes of K per chunk
   for (auto& c : e->convs) {
-    const int ksplit = c.cfg == CFG_128x128 ? 1 : (c.cfg == CFG_64x64 ? 4 : 2);
+    // k-split of the kernel that would run it (conv_ring.hip; q layers on the 64x64 tile with 128-byte chunks get a 2-way split)
+    const int ksplit = c.cfg == CFG_128x128 ? 1 : (c.cfg == CFG_64x64 ? (c.rowb == 128 ? 2 : 4) : 2);
     const int gpw = (c.rowb / 32) / ksplit;
     c.h8 = e->split_fp8 && e->mode == RTP_PREC_MIXED && e->prec == 0 && c.impl == 1 && c.split_a && c.split_w && gpw >= 2 && gpw % 2 == 0;
     if (c.split_a) { if (c.h8) e->tensors[c.in_tensor].need_q = true; else e->tensors[c.in_tensor].need_lo = true; }
@@ -556,6 +559,21 @@ int build_plan(rtp_engine* e) {
   for (size_t pi = e->pools.size(); pi-- > 0;) {  // a pool output with lo / q parts needs them in its input
     if (e->tensors[e->pools[pi].out_tensor].need_lo) e->tensors[e->pools[pi].in_tensor].need_lo = true;
     if (e->tensors[e->pools[pi].out_tensor].need_q) e->tensors[e->pools[pi].in_tensor].need_q = true;
+  }
+  {  // the input convolution without the im2col tensor: fp16 storage, 64 channels, one plain destination
+    static const char* fd = getenv("RTP_FIRST_DIRECT");  // experiments: 0 = the pack + 1x1 route
+    for (size_t si = 0; si + 1 < e->steps.size() && !(fd && fd[0] == '0'); ++si) {
+      const Step& s1 = e->steps[si];
+      if (s1.type != 1 || s1.b >= 0 || !e->convs[s1.a].first) continue;
+      ConvOp& c = e->convs[s1.a];
+      const Tensor& to = e->tensors[c.dsts[0].first];
+      if (e->prec != 0 || c.cout != 64 || c.split_w || c.dsts.size() != 1 || c.to_lowres || to.need_lo || to.need_q || e->steps[0].type != 0) break;
+      if (((size_t)3 * (e->geom[0].W + 2) * 3 + 8) * 2 > 64 * 1024) break;
+      c.direct_first = true;
+      e->steps[0] = Step{4, s1.a, -1};
+      e->steps.erase(e->steps.begin() + (long)si);
+      break;
+    }
   }
   for (auto& c : e->convs) {  // K chunks: one pass = ncp chunks of rowb bytes; split layers run 2-3 passes (h8: hi chunks + q chunks)
     c.ncp = c.nchunk;
@@ -601,6 +619,7 @@ int build_plan(rtp_engine* e) {
     c.w_bytes = (size_t)c.k_eff * c.k_eff * c.nchunk * c.CoutP * c.rowb;
     if (c.fused == 1) c.w_bytes = (size_t)c.fused_chunks * (c.split_w ? 2 : 1) * 128 * 256;
     if (c.fused == 2) c.w_bytes = (size_t)c.fused_chunks * (c.split_w ? 2 : 1) * 64 * 256;
+    if (c.direct_first) c.w_bytes = 2 * 2 * 64 * 16;
     woff = round_up_sz(woff, 256);
     c.w_off = woff;
     woff += c.w_bytes;
@@ -664,6 +683,22 @@ void pack_conv(const rtp_engine* e, const ConvOp& c, const std::vector<float>& w
     const int c16 = kk / per16, within = kk % per16;
     return ((c16 ^ conv_ring_swz(c.rowb, n)) * per16) + within;
   };
+  if (c.direct_first) {  // conv_first.hip: A-operand fragments [tile][K-step][lane][8 taps], tap k = (r*3 + s)*3 + cc
+    for (int t = 0; t < 2; ++t)
+      for (int j = 0; j < 2; ++j)
+        for (int l = 0; l < 64; ++l) {
+          const int n = t * 32 + conv_first_channel_of_row(l & 31);
+          for (int e2 = 0; e2 < 8; ++e2) {
+            const int k = j * 16 + (l >> 5) * 8 + e2;
+            float wv = 0.f;
+            if (k < 27) { const int r = k / 9, s2 = (k % 9) / 3, cc = k % 3; wv = w[((size_t)(n * 3 + cc) * 3 + r) * 3 + s2]; }
+            pw[((size_t)(t * 2 + j) * 64 + l) * 8 + e2] = (T)wv;
+          }
+        }
+    out_b->assign(c.CoutP, 0.f);
+    for (int n = 0; n < c.cout; ++n) (*out_b)[n] = b[n];
+    return;
+  }
   if (c.fused) {  // conv_pw2.hip: [chunk][part (hi, lo)][rows][128 k], rows = 128 middle channels (first) / 64 outputs (second)
     const int rows = c.fused == 1 ? 128 : 64;
     const int parts = c.split_w ? 2 : 1;
@@ -861,6 +896,28 @@ int launch_pw2_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   Q.split_w1 = A.split_w ? 1 : 0;
   Q.split_w2 = C.split_w ? 1 : 0;
   Q.h_lo = C.split_a ? 1 : 0;
+  static const char* probe = getenv("RTP_PW2_PROBE");  // diagnostics (eager mode only): phase stamps of workgroup 0
+  static int probed = 0;
+  hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+  if (probe) (void)hipStreamIsCapturing(cx.stream, &cst);
+  if (probe && cst == hipStreamCaptureStatusNone && probed < 16) {
+    unsigned long long* d = nullptr;
+    HIPCHK(e, hipMalloc((void**)&d, 32 * 8));
+    HIPCHK(e, hipMemset(d, 0, 32 * 8));
+    P.clkprobe = d;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(e, launch_conv_pw2(Q, s.b >= 0 ? 2 : 1, nimg, cx.stream));
+    HIPCHK(e, hipStreamSynchronize(cx.stream));
+    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    unsigned long long h[32];
+    HIPCHK(e, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    fprintf(stderr, "pw2 probe %s chunks %d splits %d%d%d%d (launch+sync %.1f us): ", A.name.c_str(), Q.c1_chunks, Q.x_lo_off ? 1 : 0, Q.split_w1, Q.h_lo, Q.split_w2, host_us);
+    for (unsigned i = 2; i <= h[0] && i < 32; ++i) fprintf(stderr, "%.2f ", (double)(h[i] - h[i - 1]) / 100.0);
+    fprintf(stderr, "us; total %.2f us\n", (double)(h[h[0]] - h[1]) / 100.0);
+    ++probed;
+    return RTP_OK;
+  }
   HIPCHK(e, launch_conv_pw2(Q, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   return RTP_OK;
 }
@@ -874,6 +931,22 @@ bool is_dominant_class(const rtp_engine* e, const Step& s) {
   const ConvOp& d = e->convs[e->steps[e->dominant_step].a];
   // every launch of the dominant kernel SYMBOL (what a profiler aggregates), whatever its number of MFMA passes
   return a.k == d.k && a.cin == d.cin && a.cout == d.cout && (s.b >= 0) == (e->steps[e->dominant_step].b >= 0);
+}
+
+int launch_first_step(rtp_engine* e, Ctx& cx, const Step& s, const float* input_dev, int nimg) {
+  const ConvOp& c = e->convs[s.a];
+  const Tensor& to = e->tensors[c.dsts[0].first];
+  FirstParams Q;
+  Q.in = input_dev;
+  Q.g = e->geom[0];
+  Q.g.N = nimg;
+  Q.wfrag = (const uint4*)(e->dweights + c.w_off);
+  Q.bias = (const float*)(e->dweights + c.b_off);
+  Q.out = (_Float16*)(cx.arena + to.offset);
+  Q.Cp = to.stride();
+  Q.relu = c.relu ? 1 : 0;
+  HIPCHK(e, launch_conv_first(Q, cx.stream));
+  return RTP_OK;
 }
 
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bool cap = false) {
@@ -895,6 +968,9 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bo
       if (rc) return rc;
     } else if (s.type == 3) {
       const int rc = launch_pw2_step(e, cx, s, nimg);
+      if (rc) return rc;
+    } else if (s.type == 4) {
+      const int rc = launch_first_step(e, cx, s, input_dev, nimg);
       if (rc) return rc;
     } else {
       const PoolOp& p = pools[s.a];
@@ -1977,7 +2053,14 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   double gflop = 0, mfma_gflop = 0;
   for (auto& s : e->steps) {
     if (s.type == 0) o << "step pack\n";
-    else if (s.type == 2) o << "step pool " << e->tensors[e->pools[s.a].in_tensor].name << " -> " << e->tensors[e->pools[s.a].out_tensor].name << "\n";
+    else if (s.type == 4) {
+      const ConvOp& c = e->convs[s.a];
+      const Geom& g = e->geom[c.level];
+      o << "step first " << c.name << " k 3 cin 3 cout " << c.cout << " relu " << c.relu << " passes 1 wgs " << (long)g.H * e->NI << "\n";
+      const double gf = 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->N * 1e-9;
+      gflop += gf;
+      mfma_gflop += gf;
+    } else if (s.type == 2) o << "step pool " << e->tensors[e->pools[s.a].in_tensor].name << " -> " << e->tensors[e->pools[s.a].out_tensor].name << "\n";
     else if (s.type == 3) {
       const ConvOp& A = e->convs[s.a];
       const ConvOp& C = e->convs[s.a2];
@@ -2103,6 +2186,8 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int ca
         return launch_conv_step(e, cx, s, e->NI);
       } else if (s.type == 3) {
         return launch_pw2_step(e, cx, s, e->NI);
+      } else if (s.type == 4) {
+        return launch_first_step(e, cx, s, cx.input, e->NI);
       } else {
         const PoolOp& p = e->pools[s.a];
         const Tensor& ti = e->tensors[p.in_tensor];
@@ -2121,7 +2206,7 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int ca
     HIPCHK(e, hipEventElapsedTime(&t, cx.ev[0], cx.ev[1]));
     if (ms) ms[n] = t / iters;
     double fl = 0;
-    if (s.type == 1 || s.type == 3) {
+    if (s.type == 1 || s.type == 3 || s.type == 4) {
       const Geom& g = e->geom[e->convs[s.a].level];
       for (int idx : {s.a, s.b, s.a2, s.b2}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->NI; }
     }

@@ -116,6 +116,18 @@ inline int conv_ring_swz(int chb, int row) { return chb == 256 ? (row & 15) : ((
 // NCHW fp32 [N][3][H][W] -> level-0 tensor with 32 channels = 3x3 im2col of the image
 // (channel (r*3+s)*3+c = in[c][y+r-1][x+s-1], zero outside; channels 27..31 zero).
 hipError_t launch_pack_input(int prec, const float* in_nchw, void* out, Geom g, int Cp, hipStream_t stream);
+// conv1_1 straight from the fp32 NCHW input (conv_first.hip): fp16 storage, 64 output channels, no split parts
+struct FirstParams {
+  const float* in;      // [N][3][H][W]
+  Geom g;               // level-0 geometry (N = images in this launch)
+  const uint4* wfrag;   // [tile 2][K-step 2][lane 64] A-operand fragments
+  const float* bias;    // 64 floats in the kernel's channel order == reference order
+  _Float16* out;        // halo'd NHWC destination, padded pixel 0
+  int Cp;               // its channels per pixel (elements)
+  int relu;
+};
+hipError_t launch_conv_first(const FirstParams& Q, hipStream_t stream);
+int conv_first_channel_of_row(int i);
 // 2x2 stride-2 MAX pooling between two halo'd NHWC tensors (pooling_layer.cpp:140-180).
 // lo_i / lo_o: 0, or the channel offset of the lo block of a split-precision tensor — the pooled element keeps ITS lo
 // part (the maximum of hi + lo, not two independent maxima).

@@ -83,7 +83,11 @@ def test_plan_coco_flops_and_pairing():
     pw2 = [l for l in lines if l.startswith("step pw2")]
     # 12 VGG/CPM singles + 5 stage-1 pairs + 5x7 refinement pairs = 52 launches, of which the six branch tails
     # (1x1 -> 1x1: conv5_4/5_5 and Mconv6/Mconv7 of stages 2-6) are fused two layers per launch
-    assert len(convs) == 12 + 3 + 25 and len(pw2) == 6
+    # conv1_1 reads the NCHW image itself (conv_first.hip): no pack step, no im2col tensor
+    assert lines.count("step pack") == 0 and sum(l.startswith("step first conv1_1 ") for l in lines) == 1
+    assert len(convs) == 11 + 3 + 25 and len(pw2) == 6
+    f16x3 = _plan_lines(precision=3)   # split weights: conv1_1 takes the generic route (pack + 1x1 with K = 32)
+    assert f16x3.count("step pack") == 1 and any(l.startswith("step conv conv1_1 ") for l in f16x3)
     assert sum(" + " in l for l in convs) == 28 and all(l.count(" + ") == 2 for l in pw2)
     assert any("conv4_4_CPM" in l and "dsts 6" in l for l in convs)  # own tensor + 5 concat slices
     assert [l for l in pw2 if "Mconv7_stage6" in l][0].endswith("lowres 1")
