@@ -76,7 +76,8 @@ __device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntil
 // to every destination tensor (interior pixels only; the halo stays zero).  One integer division
 // per item instead of one per element, no idle waves.
 // acc layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN>
+// ILV: fragment i of a wave covers the pixels TM*r + i instead of 32*i + r (conv_ring.hip, interleaved fragment rows).
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN, bool ILV = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
                                               int kg, int wrem, int wm0, int wn0, int lane, int img, int m0, int n0) {
   static_assert(KSPLIT * BM * BN * 4 <= 64 * 1024, "partials fit in 64 KiB of LDS");
@@ -88,7 +89,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+        const int r32 = (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+        const int row = ILV ? wm0 + TM * r32 + i : wm0 + i * 32 + r32;
         const int col = wn0 + j * 32 + lrow;
         red[(kg * BM + row) * BN + col] = acc[i][j][q];
       }

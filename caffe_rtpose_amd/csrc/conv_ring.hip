@@ -25,11 +25,49 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#ifndef ILV_EXP
+#define ILV_EXP 0
+#endif
 
 namespace rtp {
 
 template <int CHB> __device__ __host__ __forceinline__ int ring_swz(int row) {
   return CHB == 256 ? (row & 15) : ((row >> 1) & 7);
+}
+
+// A-strip swizzle.  ILV (interleaved fragment rows, see the consumer loop): the 16 lanes of a ds_read_b128 group read rows
+// c + TM*l, so the swizzle key is row / TM (CHB = 256: 16 distinct 16-byte slots again; CHB = 128 keeps the plain key and
+// takes a 2-way conflict on the few fresh reads that remain).
+template <int CHB, int TM, bool ILV> __device__ __forceinline__ int ring_swz_a(int row) {
+  if constexpr (ILV && CHB == 256) return (row / TM) & 15;
+  else return ring_swz<CHB>(row);
+}
+
+// every lane takes the value of the next higher lane (v_mov_b32_dpp wave_shl:1).  bound_ctrl: lane 63 (no source) gets 0 and
+// the destination is not tied to an "old" value (with old = src hipcc emitted a v_mov in front of every DPP move)
+__device__ __forceinline__ uint4 lanes_down1(const uint4& v) {
+#if ILV_EXP == 2
+  return v;
+#endif
+  uint4 r;
+  r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130, 0xf, 0xf, true);
+  r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x130, 0xf, 0xf, true);
+  r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x130, 0xf, 0xf, true);
+  r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x130, 0xf, 0xf, true);
+  return r;
+}
+
+// ds_read_b128 into `v` for the lanes of `mask` only; the other lanes of v keep their value.  Hidden in asm on purpose: as a
+// divergent `if` the partial overwrite of a fragment made hipcc spill ~800 registers in the fp8 variant (8-register MFMA
+// operands).  The compiler does not see this LDS read, so EVERY use of the fragment must sit behind an explicit lgkmcnt(0)
+// (the wait at the top of the next tap; one more in front of the last tap).
+typedef unsigned uint4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_read_lanes(uint4& v, unsigned lds_addr, unsigned long long mask) {
+  uint4v_t t = __builtin_bit_cast(uint4v_t, v);
+  unsigned long long keep;
+  asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\ts_nop 0\n\tds_read_b128 %0, %2\n\ts_mov_b64 exec, %1"
+               : "+v"(t), "=&s"(keep) : "v"(lds_addr), "s"(mask));
+  v = __builtin_bit_cast(uint4, t);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_>
@@ -181,8 +219,15 @@ constexpr int ring_wait_count(int s) {
 //   15 = no per-tap barriers (and no counted waits), 16 = 15 + no ds_reads (a bare MFMA stream)
 //   100 = the fp8-compensated variant of the kernel (layers with q chunks, ConvParams::q_from): its own instantiation, so that
 //       the plain kernel's register allocation (254 VGPRs with the front-loaded reads) is not disturbed; reads one per MFMA
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0>
+//   ILV (wave-specialised kernels): A fragments are NOT re-read from LDS for every tap.  Fragment i of a wave holds the pixels
+//       TM*l + i (l = lane & 31) instead of 32*i + l, so tap s+1's fragment i < TM-1 is tap s's fragment i+1 (a register rename
+//       in the unrolled code) and fragment TM-1 is tap s's fragment 0 moved down one lane (4 v_mov_b32_dpp) with ONE fresh row
+//       read by lanes 31 / 63.  Only the first tap of a strip reads all A fragments from LDS: 6/7 (7x7) or 2/3 (3x3) of the A
+//       reads = 43 % / 33 % of all ds_read traffic disappear.  The ablation showed the launch is bound by the matrix pipe at a
+//       clock that drops when the LDS is busy (no ds_reads: 2.2 instead of 1.8 GHz); same MFMA order, bit-identical results.
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0, bool ILV = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvParams P) {
+  static_assert(!ILV || SPEC, "interleaved fragment rows exist in the wave-specialised kernels only");
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
   constexpr int A_PW = TR::A_PW, B_PW = TR::B_PW, TM = TR::TM, TN = TR::TN;
@@ -228,7 +273,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     const int j = wave * A_PW + q;
     const int row = j * RPI + lane / NCH;
     const int cphys = lane % NCH;
-    a_voff[q] = (unsigned)(row * (int)pix_bytes + ((cphys ^ ring_swz<CHB>(row)) * 16) - (q & 3) * 1024);
+    a_voff[q] = (unsigned)(row * (int)pix_bytes + ((cphys ^ ring_swz_a<CHB, TR::TM, ILV>(row)) * 16) - (q & 3) * 1024);
   }
   const unsigned b_voff = (unsigned)(wave * B_PW * 1024 + lane * 16);
   const unsigned sA_addr = lds_addr_of(sA) + wave * A_PW * 1024;
@@ -352,7 +397,24 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(3);
-    read_frags(0, 0, 0, fa, fb);
+    // ILV: address of the 16-byte piece `cl` of this lane's row of A fragment i for tap s
+    auto a_ilv = [&](int i, int s, int abuf_, int cl) __attribute__((always_inline)) {
+      const int row = wm0 + TM * lrow + i + s;
+      return (const uint4*)(sA + abuf_ * TR::A_BYTES + row * CHB + ((cl ^ ring_swz_a<CHB, TM, true>(row)) * 16));
+    };
+    if constexpr (ILV) {
+      const unsigned char* pb0 = pb_lane;
+#pragma unroll
+      for (int gi = 0; gi < GPW; ++gi) {
+        const int cl = 2 * (kg * GPW + gi) + lhalf;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[gi][i] = *a_ilv(i, 0, 0, cl);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[gi][j] = *(const uint4*)(pb0 + j * 32 * CHB + ((cl ^ bswz) * 16));
+      }
+    } else {
+      read_frags(0, 0, 0, fa, fb);
+    }
     if constexpr (VAR == 17) {
 #pragma unroll
       for (int gi = 0; gi < GPW; ++gi) {
@@ -374,11 +436,24 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     // addresses for both chunk types.  For a q chunk that hands lane half lhalf the 16-byte pieces #lhalf and #(2+lhalf) of
     // each 64-byte k-block instead of 32 contiguous bytes; A and B are read alike, so the MFMA still pairs equal K positions
     // (a dot product does not care about the order of its terms).
-    auto read_one_c = [&](auto rq_tag, int idx, const unsigned char* pa, const unsigned char* pb, int aswz) __attribute__((always_inline)) {
+    auto read_one_c = [&](auto s_tag, int idx, const unsigned char* pa, const unsigned char* pb, int aswz, int abuf_) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_tag)::value;
       const int gi = idx / (TM + TN), q = idx % (TM + TN);
       const int cl = 2 * (kg * GPW + gi) + lhalf;
-      if (q < TM) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
-      else nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
+      if (q >= TM) nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
+      else if constexpr (!ILV) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
+      else if constexpr (s == 0) na_[gi][q] = *a_ilv(q, 0, abuf_, cl);       // first tap of a strip: fresh rows
+      else if (q < TM - 1) na_[gi][q] = fa[gi][q + 1];                        // pixels TM*l + q + s + 1 = fragment q+1 of tap s
+      else na_[gi][q] = lanes_down1(fa[gi][0]);                              // pixels TM*(l+1) + s: fragment 0 of the lane above
+    };
+    // ILV: the one row the shift cannot supply (lanes 31 and 63 of fragment TM-1), all k-groups in one divergent region
+    auto read_boundary_c = [&](auto s_tag, int abuf_) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_tag)::value;
+#if ILV_EXP != 1
+#pragma unroll
+      for (int gi = 0; gi < GPW; ++gi)
+        lds_read_lanes(na_[gi][TM - 1], lds_addr_of((const unsigned char*)a_ilv(TM - 1, s, abuf_, 2 * (kg * GPW + gi) + lhalf)), 0x8000000080000000ull);
+#endif
     };
     // MFMA #m of the tap being multiplied.  MQ: fp8 compensation tap — k-block jj of this wave is the (kg*NKB + jj)-th of the
     // chunk: even = a_lo8 x W8, odd = a8 x W_lo8.
@@ -419,15 +494,17 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
 #pragma unroll
       for (int m = 0; m < NMMA_C; ++m) {
         mma_one_c(mq_tag, m);
-        if constexpr (VAR != 4 && VAR != 100 && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded over the first half of the tap
+        if constexpr (VAR != 4 && (VAR != 100 || ILV) && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded over the first half of the tap
           constexpr int HALF = NMMA_C / 2 > 0 ? NMMA_C / 2 : 1;
           if (m < HALF) {
 #pragma unroll
-            for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(rq_tag, rd, pa, pb, aswz);
+            for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(s_tag, rd, pa, pb, aswz, abuf);
           }
-        } else if constexpr (VAR == 4 || VAR == 100) {
+          if constexpr (ILV && s != 0) { if (m == HALF - 1) read_boundary_c(s_tag, abuf); }
+        } else if constexpr (VAR == 4 || (VAR == 100 && !ILV)) {
 #pragma unroll
-          for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(rq_tag, rd, pa, pb, aswz);
+          for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(s_tag, rd, pa, pb, aswz, abuf);
+          if constexpr (ILV && s != 0) { if (m == NMMA_C - 1) read_boundary_c(s_tag, abuf); }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -470,6 +547,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       for (int sc = 1; sc < nstrips; ++sc) { cstep(std::integral_constant<int, 0>{}, QF, QF); strip_tail(QF); }
     }
     // last tap
+    if constexpr (ILV) {  // lgkmcnt(0): the masked boundary reads are invisible to the compiler; no MFMA may be scheduled above the wait
+      wait_vmcnt<63>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (CANQ && last_q) {
 #pragma unroll
       for (int m = 0; m < NKB * TM * TN; ++m) mma_one_c(QT, m);
@@ -479,7 +560,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     }
     wait_vmcnt<63>();
     __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
-    conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
+    conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
     if (P.tstamp && tid == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       atomicMax(&P.tstamp[1], (unsigned long long)wall_clock64());
@@ -581,18 +662,23 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0>
+#ifndef RTP_RING_NO_LAUNCHERS  // (tools/ring_probe.hip instantiates single kernels to inspect their ISA)
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0, bool ILV = false>
 static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream);
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
   if (P.q_from > 0) {  // fp8-compensated layer: always the wave-specialised kernel, q instantiation
-    if constexpr (std::is_same<T, _Float16>::value && ((CHB / 32) / KSPLIT) % 2 == 0)
+    if constexpr (std::is_same<T, _Float16>::value && ((CHB / 32) / KSPLIT) % 2 == 0) {
+      if (P.ilv) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100, true>(P, nprob, N, stream);
       return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100>(P, nprob, N, stream);
-    else
+    } else
       return hipErrorInvalidValue;
   }
   if (P.spec) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+      if (P.ilv && P.variant == 0) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 0, true>(P, nprob, N, stream);
+    }
     // experiment variants exist for the dominant plan only (fp16, 7x7, tile 128x64, 256-byte chunks)
     if constexpr (std::is_same<T, _Float16>::value && BM == 128 && BN == 64 && KS == 7 && CHB == 256) {
       switch (P.variant) {
@@ -613,10 +699,10 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
   return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, false>(P, nprob, N, stream);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR, bool ILV>
 static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
-  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC, VAR>;
+  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC, VAR, ILV>;
   static std::atomic<unsigned> attr_mask{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -676,5 +762,7 @@ hipError_t launch_conv_ring(int prec, int cfg, int ks, int chb, const ConvParams
   }
   return hipErrorInvalidValue;
 }
+
+#endif  // RTP_RING_NO_LAUNCHERS
 
 }  // namespace rtp

@@ -370,7 +370,15 @@ int build_plan(rtp_engine* e) {
   for (int l = 0; l < e->nlevels; ++l) {
     Geom g;
     g.N = e->NI; g.H = e->cfg.net_h >> l; g.W = e->cfg.net_w >> l; g.halo = level_halo[l];
-    g.Hp = g.H + 2 * g.halo; g.Wp = g.W + 2 * g.halo; g.img_pix = (long)g.Hp * g.Wp;
+    // ONE zero gap of `halo` pixels between consecutive rows serves as the right halo of row y and the left halo of row y+1
+    // (flat addressing: pixel p's tap (r,s) is p + (r-pad)*Wp + (s-pad), so x+pad past the row end lands in the gap and x-pad
+    // before the row start lands in the previous row's gap).  Wp = W + halo instead of W + 2*halo: 3.4 % fewer GEMM rows at
+    // 1/8 resolution (85 instead of 88 per row) and 31 instead of 32 M-tiles of 128 per 46x82 image — a launch of the paired
+    // 7x7 layers at batch_frames = 2 is 248 workgroups, not 256: it no longer needs EVERY CU at once.
+    // The last pixel's far corner tap reads 2 pixels past Hp*Wp: the next image's top halo / the tensor's zero guard.
+    static const char* sh = getenv("RTP_HALO_SHARED");  // experiments: 0 = a halo on both sides of every row
+    const bool shared = !(sh && sh[0] == '0');
+    g.Hp = g.H + 2 * g.halo; g.Wp = g.W + (shared ? 1 : 2) * g.halo; g.img_pix = (long)g.Hp * g.Wp;
     e->geom[l] = g;
   }
   e->low_w = e->cfg.net_w / 8;
@@ -855,6 +863,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
     P.spec = (sp && sp[0] == '0') ? 0 : 1;  // wave-specialised ring kernels (default); 0 = every wave does both
     static const char* rv = getenv("RTP_RING_VAR");
     P.variant = rv ? atoi(rv) : 0;
+    static const char* il = getenv("RTP_RING_ILV");
+    P.ilv = (il && il[0] == '1') ? 1 : 0;
   }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
@@ -1140,9 +1150,33 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
 }
 int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev, bool materialize = false) { return launch_batch(e, cx, 1, input_dev, materialize); }
 
+// experiments: RTP_CONV_PRIO / RTP_POST_PRIO = a stream priority (hipDeviceGetStreamPriorityRange: lower number = higher priority)
+// for the batch (conv stack) streams / the per-frame post-processing streams; unset = default-priority streams
+hipError_t make_stream(hipStream_t* s, const char* env_name) {
+  // RTP_POST_CUS = n: the post-processing streams may only use n CUs (hipExtStreamCreateWithCUMask; the KFD interleaves the
+  // mask bits over the XCDs, so the low 8 bits are one CU in each of the 8 XCDs).  With the shared-halo geometry a convolution
+  // launch at 1/8 resolution is 248 workgroups: 8 CUs can belong to other frames' post-processing without costing it a second round.
+  if (!strcmp(env_name, "RTP_POST_PRIO")) {
+    const char* c = getenv("RTP_POST_CUS");
+    const int n = c ? atoi(c) : 0;
+    if (n > 0 && n < 256) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < n; ++b) mask[b >> 5] |= 1u << (b & 31);
+      return hipExtStreamCreateWithCUMask(s, 8, mask);
+    }
+  }
+  const char* v = getenv(env_name);
+  if (!v || !v[0]) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  int pr = atoi(v);
+  pr = std::max(greatest, std::min(least, pr));
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, pr);
+}
+
 int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   if (share_stream) sl.stream = cx.stream;
-  else { HIPCHK(e, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)); sl.own_stream = true; }
+  else { HIPCHK(e, make_stream(&sl.stream, "RTP_POST_PRIO")); sl.own_stream = true; }
   const size_t res_floats = (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w;
   HIPCHK(e, hipMalloc((void**)&sl.resized, res_floats * sizeof(float)));
   const size_t peak_floats = (size_t)e->num_parts * (e->max_peaks + 1) * 3;
@@ -1168,7 +1202,7 @@ int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
 }
 
 int alloc_ctx(rtp_engine* e, Ctx& cx) {
-  HIPCHK(e, hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
+  HIPCHK(e, make_stream(&cx.stream, "RTP_CONV_PRIO"));
   HIPCHK(e, hipMalloc((void**)&cx.arena, e->arena_bytes));
   HIPCHK(e, hipMemset(cx.arena, 0, e->arena_bytes));
   const size_t in_floats = (size_t)e->NI * 3 * e->cfg.net_h * e->cfg.net_w;
@@ -1182,7 +1216,8 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   cx.slot.resize(e->B);
   for (int j = 0; j < e->B; ++j) {
     int rc;
-    if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0))) return rc;
+    static const char* own0 = getenv("RTP_POST_OWN0");  // experiments: 1 = frame 0's post-processing chain also gets its own stream
+    if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0 && !(own0 && own0[0] == '1')))) return rc;
   }
   return RTP_OK;
 }

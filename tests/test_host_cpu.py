@@ -331,7 +331,7 @@ def test_bit_exact_kernels_contain_no_packed_f32_valu():
     out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "caffe_rtpose_amd", "csrc"), "check-nopk"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     counts = [int(x) for x in out.stdout.split()]
-    assert counts == [0, 0, 0, 0, 0, 0], out.stdout   # postproc, preproc, render, conv_ring, conv_igemm, conv_pw2
+    assert counts == [0] * 7, out.stdout   # postproc, preproc, render, conv_ring, conv_igemm, conv_pw2, conv_first
 
 
 def test_caffemodel_blobshape_lengths_are_bounds_checked(tmp_path):

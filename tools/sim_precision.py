@@ -66,6 +66,55 @@ def conv_h8(x, w, b, pad, comp_a=True, comp_w=True):
     return y
 
 
+MINIFLOAT = {"e2m1": (1, 0, 2, 6.0), "e2m3": (3, 0, 2, 7.5), "e3m2": (2, -2, 4, 28.0)}  # mantissa bits, min normal exponent, max exponent, max value
+H4_FMT = "e2m1"
+
+
+H4_FMT_W = None   # weights' format when it differs from the activations'
+
+
+def fp4_round(t, fmt=None):
+    """nearest value of an MX minifloat format (round half to even), |t| clamped to the format maximum; subnormals kept"""
+    m, emin, emax, vmax = MINIFLOAT[fmt or H4_FMT]
+    a = t.abs().clamp(max=vmax).double()
+    e = torch.floor(torch.log2(a.clamp(min=2.0 ** -60))).clamp(min=emin, max=emax)
+    q = 2.0 ** (e - m)
+    return (torch.round(a / q) * q).clamp(max=vmax).float() * t.sign()
+
+
+def blk_exp(x, block):
+    """per (pixel, `block` channels) exponent s with max|x| <= 6 * 2^s (smallest such), as a tensor broadcastable to x (channels padded)"""
+    n, c, h, w = x.shape
+    cp = (c + block - 1) // block * block
+    xp = F.pad(x, (0, 0, 0, 0, 0, cp - c))
+    m = xp.abs().view(n, cp // block, block, h, w).amax(2, keepdim=True)
+    vmax = MINIFLOAT[H4_FMT][3]
+    s = torch.ceil(torch.log2((m / vmax).clamp(min=2.0 ** -60)))   # smallest s with max <= vmax * 2^s
+    return s.expand(n, cp // block, block, h, w).reshape(n, cp, h, w)[:, :c]
+
+
+def conv_h4(x, w, b, pad, comp_a=True, comp_w=True, block=32, lo_shift=11):
+    """hi*hi in fp16 + fp4 (e2m1, MX block scales) error compensation: a_lo4 * W4 + a4 * W_lo4.
+    activations: one E8M0 scale per (pixel, 32 channels) from the block maximum; weights: one static scale per layer"""
+    xh = x.half().float(); wh = w.half().float()
+    y = F.conv2d(xh, wh, b, padding=pad)
+    s = blk_exp(x, block)
+    fw = H4_FMT_W or H4_FMT
+    sw = float(np.ceil(np.log2(float(w.abs().max()) / MINIFLOAT[fw][3])))
+    if comp_a:
+        xlo = x - xh
+        sl = s - lo_shift
+        a4 = fp4_round(xlo / 2.0 ** sl) * 2.0 ** sl
+        w4 = fp4_round(wh / 2.0 ** sw, fw) * 2.0 ** sw
+        y = y + F.conv2d(a4, w4, None, padding=pad)
+    if comp_w:
+        wlo = w - wh
+        a4 = fp4_round(xh / 2.0 ** s) * 2.0 ** s
+        w4 = fp4_round(wlo / 2.0 ** (sw - lo_shift), fw) * 2.0 ** (sw - lo_shift)
+        y = y + F.conv2d(a4, w4, None, padding=pad)
+    return y
+
+
 def layers(model=0):
     """(name, cin, cout, k, relu, section) in execution order + topology handled in forward()."""
     nL1, nL2 = (38, 19) if model == 0 else (28, 16)
@@ -84,7 +133,9 @@ def forward(x, wm, am, over, model=0):
             if pat.startswith("re/") and re.search(pat[3:], name):
                 w_mode, a_mode = v
         w, b = synth(name, cout, cin, k)
-        if w_mode == "h8" or a_mode == "h8":
+        if w_mode == "h4" or a_mode == "h4":
+            y = conv_h4(t, w, b, k // 2, comp_a=(a_mode == "h4"), comp_w=(w_mode == "h4"), block=H4_BLOCK, lo_shift=H4_LO)
+        elif w_mode == "h8" or a_mode == "h8":
             y = conv_h8(t, w, b, k // 2, comp_a=(a_mode == "h8"), comp_w=(w_mode == "h8"))
         else:
             y = F.conv2d(rnd(t, a_mode), rnd(w, w_mode), b, padding=k // 2)
@@ -129,13 +180,23 @@ def forward(x, wm, am, over, model=0):
     return torch.cat([outs[1], outs[0]], 1)  # concat_stage7: heat maps first
 
 
+H4_BLOCK = 32
+H4_LO = 11
+
+
 def main():
+    global H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W
     ap = argparse.ArgumentParser()
+    ap.add_argument("--h4_block", type=int, default=32)
+    ap.add_argument("--h4_lo", type=int, default=11)
+    ap.add_argument("--h4_fmt", default="e2m1", choices=sorted(MINIFLOAT))
+    ap.add_argument("--h4_fmt_w", default=None, choices=sorted(MINIFLOAT))
     ap.add_argument("--w", type=int, default=160)
     ap.add_argument("--h", type=int, default=96)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("modes", nargs="+")
     a = ap.parse_args()
+    H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W = a.h4_block, a.h4_lo, a.h4_fmt, a.h4_fmt_w
     torch.set_num_threads(os.cpu_count())
     rs = np.random.RandomState(a.seed)
     x = torch.from_numpy((rs.randint(0, 256, size=(1, 3, a.h, a.w)).astype(np.float32) / 256.0 - 0.5))
