@@ -58,6 +58,7 @@ SIGNATURES = {
     "rtp_debug_preprocess": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, fp, C.POINTER(C.c_ubyte), fp]),
     "rtp_flush": (C.c_int, [vp]),
     "rtp_collect_rendered": (C.c_int, [vp, C.POINTER(C.c_uint64), fp, ip, C.POINTER(C.c_ubyte)]),
+    "rtp_render": (C.c_int, [vp, C.POINTER(C.c_ubyte), fp, C.c_int, C.c_int, C.c_int, fp, C.POINTER(C.c_ubyte)]),
     "rtp_decode_image": (C.c_int, [C.POINTER(C.c_ubyte), C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t, ip, ip]),
     "rtp_codec_last_error": (C.c_char_p, []),
     "rtp_encode_jpeg": (C.c_long, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_size_t]),

@@ -1086,11 +1086,20 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
         HIPCHK(e, hipHostMalloc((void**)&sl.render_host, dbytes, hipHostMallocDefault));
         HIPCHK(e, hipMalloc((void**)&sl.render_tab, render_tab_floats(RTP_MAX_PEOPLE) * sizeof(float)));
       }
-      RenderParams rp;
-      rp.src = sl.disp_dev; rp.dst = sl.render_dev; rp.w = e->cfg.disp_w; rp.h = e->cfg.disp_h;
-      rp.poses = sl.joints; rp.num_people = sl.num_people; rp.tab = sl.render_tab;
-      rp.model = e->model; rp.googly = 0; rp.max_people = RTP_MAX_PEOPLE;
-      HIPCHK(e, launch_render(rp, sl.stream));
+      if (e->cfg.render == 1) {
+        RenderParams rp;
+        rp.src = sl.disp_dev; rp.dst = sl.render_dev; rp.w = e->cfg.disp_w; rp.h = e->cfg.disp_h;
+        rp.poses = sl.joints; rp.num_people = sl.num_people; rp.tab = sl.render_tab;
+        rp.model = e->model; rp.googly = 0; rp.max_people = RTP_MAX_PEOPLE;
+        HIPCHK(e, launch_render(rp, sl.stream));
+      } else {  // --part_to_show view: needs the frame's net-resolution maps, which the production path never builds
+        if (!(materialize || skip || (unf && unf[0] == '1')) && (rc = run_resize(e, cx, j))) return rc;
+        RenderViewParams vp;
+        vp.src = sl.disp_dev; vp.dst = sl.render_dev; vp.w = e->cfg.disp_w; vp.h = e->cfg.disp_h;
+        vp.maps = sl.resized; vp.net_w = e->cfg.net_w; vp.net_h = e->cfg.net_h;
+        vp.model = e->model; vp.part_to_show = e->cfg.render - 1;
+        HIPCHK(e, launch_render_view(vp, sl.stream));
+      }
       HIPCHK(e, hipMemcpyAsync(sl.render_host, sl.render_dev, dbytes, hipMemcpyDeviceToHost, sl.stream));
     }
     HIPCHK(e, hipMemcpyAsync(sl.host_out + 4, sl.joints, jbytes, hipMemcpyDeviceToHost, sl.stream));
@@ -1405,6 +1414,12 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (cfg->num_scales < 1 || cfg->num_scales > 16) return fail(nullptr, RTP_EINVAL, "num_scales %d out of range", cfg->num_scales);
   if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 64) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
   if (cfg->batch_frames < 0 || cfg->batch_frames > 16) return fail(nullptr, RTP_EINVAL, "batch_frames %d out of range", cfg->batch_frames);
+  {  // render = 1 + part_to_show: the view must stay inside the model's maps (44 MPI: parts + background + 28 PAFs; COCO: 18 parts, "all", 20 PAF views)
+    const int part = cfg->render - 1;
+    const bool mpi = cfg->model == RTP_MODEL_MPI_15;
+    if (cfg->render < 0 || (cfg->render > 1 && (mpi ? part > 44 : part > 39)))
+      return fail(nullptr, RTP_EINVAL, "render %d: part_to_show %d is outside the model's maps", cfg->render, part);
+  }
   if (cfg->precision < RTP_PREC_FP16 || cfg->precision > RTP_PREC_F16X3) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
   if (cfg->exec_mode != RTP_EXEC_GRAPH && cfg->exec_mode != RTP_EXEC_EAGER) return fail(nullptr, RTP_EINVAL, "unknown exec_mode %d", cfg->exec_mode);
   if (cfg->disp_w < 1 || cfg->disp_h < 1) return fail(nullptr, RTP_EINVAL, "bad display resolution");
@@ -1842,6 +1857,49 @@ int rtp_connect(rtp_engine* e, const float* resized, const float* peaks, float* 
   if (n < 0) { if (num_people) *num_people = 0; return fail(e, RTP_ERANGE, "connect: PAF sample coordinate out of range"); }
   if (num_people) *num_people = n;
   if (joints && n > 0) HIPCHK(e, hipMemcpy(joints, cx.slot[0].joints, (size_t)n * e->num_parts * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return RTP_OK;
+}
+
+// render() of rtpose.cpp:270-299 on caller data: the pose overlay or one of the --part_to_show views
+int rtp_render(rtp_engine* e, const unsigned char* display_bgr, const float* joints, int num_people, int part_to_show, int googly,
+               const float* resized_host, unsigned char* out_bgr) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!display_bgr || !out_bgr || num_people < 0 || (num_people > 0 && !joints)) return RTP_EINVAL;
+  // the last map a view reads: MPI part_to_show - 1; COCO heat maps <= 18, PAF view p reads channels up to 2*(p-20)-2+19+1
+  const int last_map = e->model != 0 ? part_to_show - 1 : (part_to_show <= 19 ? 17 : (part_to_show == 20 ? 56 : 2 * (part_to_show - 20) + 18));
+  if (part_to_show < 0 || (part_to_show > 0 && (!resized_host || last_map >= e->heat_channels)))
+    return fail(e, RTP_EINVAL, "part_to_show %d is outside the model's %d maps", part_to_show, e->heat_channels);
+  Ctx& cx = e->ctx[0];
+  Slot& sl = cx.slot[0];
+  const int w = e->cfg.disp_w, h = e->cfg.disp_h;
+  const size_t dbytes = (size_t)w * h * 3;
+  if (!sl.render_dev) {
+    HIPCHK(e, hipMalloc((void**)&sl.render_dev, dbytes));
+    HIPCHK(e, hipHostMalloc((void**)&sl.render_host, dbytes, hipHostMallocDefault));
+    HIPCHK(e, hipMalloc((void**)&sl.render_tab, render_tab_floats(RTP_MAX_PEOPLE) * sizeof(float)));
+  }
+  if (!sl.disp_dev) HIPCHK(e, hipMalloc((void**)&sl.disp_dev, dbytes));
+  HIPCHK(e, hipMemcpy(sl.disp_dev, display_bgr, dbytes, hipMemcpyHostToDevice));
+  if (part_to_show == 0) {
+    const int n = std::min(num_people, (int)RTP_MAX_PEOPLE);
+    if (n > 0) HIPCHK(e, hipMemcpy(sl.joints, joints, (size_t)n * e->num_parts * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(sl.num_people, &n, sizeof(int), hipMemcpyHostToDevice));
+    RenderParams rp;
+    rp.src = sl.disp_dev; rp.dst = sl.render_dev; rp.w = w; rp.h = h;
+    rp.poses = sl.joints; rp.num_people = sl.num_people; rp.tab = sl.render_tab;
+    rp.model = e->model; rp.googly = googly ? 1 : 0; rp.max_people = RTP_MAX_PEOPLE;
+    HIPCHK(e, launch_render(rp, sl.stream));
+  } else {
+    HIPCHK(e, hipMemcpy(sl.resized, resized_host, (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyHostToDevice));
+    RenderViewParams vp;
+    vp.src = sl.disp_dev; vp.dst = sl.render_dev; vp.w = w; vp.h = h;
+    vp.maps = sl.resized; vp.net_w = e->cfg.net_w; vp.net_h = e->cfg.net_h;
+    vp.model = e->model; vp.part_to_show = part_to_show;
+    HIPCHK(e, launch_render_view(vp, sl.stream));
+  }
+  HIPCHK(e, hipStreamSynchronize(sl.stream));
+  HIPCHK(e, hipMemcpy(out_bgr, sl.render_dev, dbytes, hipMemcpyDeviceToHost));
   return RTP_OK;
 }
 

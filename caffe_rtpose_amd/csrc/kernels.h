@@ -170,6 +170,16 @@ struct RenderParams {
 };
 hipError_t launch_render(const RenderParams& p, hipStream_t stream);
 size_t render_tab_floats(int max_people);
+// the --part_to_show views of render() (rtpose.cpp:270-299): one heat-map channel, all part maps, or PAF channels over the frame
+struct RenderViewParams {
+  const unsigned char* src;  // display image, u8 BGR HWC (device)
+  unsigned char* dst;
+  int w, h;
+  const float* maps;         // net-resolution maps [C][net_h][net_w] (what the Nms layer reads), device
+  int net_w, net_h;
+  int model, part_to_show;   // part_to_show > 0 as FLAGS_part_to_show
+};
+hipError_t launch_render_view(const RenderViewParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
 // Post-processing (bit-exact restatements of the reference's CUDA kernels / host loop).

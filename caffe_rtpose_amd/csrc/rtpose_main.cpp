@@ -256,7 +256,7 @@ void worker(int widx, int device, int* status) {
   cfg.precision = F.precision == "fp32" ? RTP_PREC_FP32 : F.precision == "fp16" ? RTP_PREC_FP16 : F.precision == "f16x3" ? RTP_PREC_F16X3 : RTP_PREC_MIXED;
   cfg.frames_in_flight = F.frames_in_flight;
   cfg.batch_frames = F.batch_frames;
-  cfg.render = F.write_frames.empty() ? 0 : 1;
+  cfg.render = F.write_frames.empty() ? 0 : 1 + F.part_to_show;  // render() of rtpose.cpp:270-299: pose overlay or a --part_to_show view
   rtp_engine* e = nullptr;
   if (rtp_engine_create(&cfg, &e) != RTP_OK) {
     fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));

@@ -312,6 +312,18 @@ class Engine:
         self._chk(lib.rtp_post_from_lowres(self.h, _f(lowres), _f(peaks), _f(joints), C.byref(n)))
         return peaks, joints[: n.value].copy(), n.value
 
+    def render(self, display_bgr, joints, num_people, part_to_show=0, googly=0, resized=None):
+        """render() of rtpose.cpp:270-299 on caller data: pose overlay (part_to_show 0) or a heat-map / PAF view of `resized`."""
+        img = np.ascontiguousarray(display_bgr, np.uint8)
+        assert img.shape == (self.cfg.c.disp_h, self.cfg.c.disp_w, 3), img.shape
+        j = np.ascontiguousarray(joints, np.float32).reshape(-1)
+        if j.size == 0:
+            j = np.zeros(3, np.float32)
+        res = None if resized is None else np.ascontiguousarray(resized, np.float32)
+        out = np.empty_like(img)
+        self._chk(lib.rtp_render(self.h, _u8(img), _f(j), int(num_people), int(part_to_show), int(googly), _f(res) if res is not None else None, _u8(out)))
+        return out
+
     def collect_rendered(self):
         tag = C.c_uint64()
         n = C.c_int()

@@ -78,8 +78,10 @@ typedef struct rtp_config {
                             * B*num_scales images (bigger tiles fill the 256 CUs), then post-      *
                             * processes each frame on its own stream.  Per-frame results do not    *
                             * depend on B.  ceil(frames_in_flight / B) batches are in flight.       */
-  int render;              /* 1: also draw the pose overlay on the display image (render_pose_*,   *
-                            * renderFunctions.cu; part_to_show == 0) for rtp_collect_rendered        */
+  int render;              /* 0: off.  1 + FLAGS_part_to_show: rtp_collect_rendered also returns the  *
+                            * display image as render() (rtpose.cpp:270-299) draws it: 1 = the pose    *
+                            * overlay (render_pose_*, renderFunctions.cu), 2.. = heat-map / PAF view   *
+                            * part_to_show = render - 1 (that frame's resized map is then materialised) */
   int exec_mode;           /* RTP_EXEC_*: how a batch's ~45 launches reach the GPU.  Replaces the  *
                             * reference's per-call layer walk (net.cpp:544-556 ForwardFromTo).       */
   const char* split_layers;/* RTP_PREC_MIXED only; NULL = default set.  Comma-separated rules, each *
@@ -163,6 +165,16 @@ int rtp_resize(rtp_engine* e, const float* lowres_host, float* resized_host);
  * imresize_layer.cu, so the results equal rtp_resize -> rtp_nms -> rtp_connect bit for bit.
  * lowres: [num_scales][heat_channels][low_h][low_w]; peaks in/out like rtp_nms (may be NULL). */
 int rtp_post_from_lowres(rtp_engine* e, const float* lowres_host, float* peaks_host, float* joints_host, int* num_people);
+
+/* render() of rtpose.cpp:270-299 on caller data (parity tap of the renderer, and the --part_to_show views of --write_frames):
+ * display_bgr / out_bgr = u8 BGR HWC at cfg.disp_w x cfg.disp_h (what the producer's canvas holds, rtpose.cpp:349, and what the
+ * post-processing thread makes of the rendered canvas, :1287-1296); joints [num_people][num_parts][3] in display coordinates.
+ * part_to_show = FLAGS_part_to_show: 0 = pose overlay (render_pose_coco_parts / render_pose_29parts; googly = the GUI's
+ * googly-eyes toggle, COCO only), 1..parts = one heat map, parts+1 (COCO) = all part maps, above = PAF views
+ * (render_coco_aff).  resized_host (heat_channels x net_h x net_w, rtp_resize's output) is only read when part_to_show != 0.
+ * RTP_EINVAL for a part_to_show outside the model's maps (the reference would read past its blob). */
+int rtp_render(rtp_engine* e, const unsigned char* display_bgr, const float* joints, int num_people, int part_to_show, int googly,
+               const float* resized_host, unsigned char* out_bgr);
 
 /* NmsLayer::Forward_gpu on caller data: resized (C x H x W) -> peaks (num_parts x (max_peaks+1) x 3).
  * peaks is IN/OUT: slots the kernel does not write keep the caller's contents. */

@@ -12,6 +12,7 @@ mkdir -p "$OUT/gen"
 RT="$REF/examples/rtpose/rtpose.cpp"
 IM="$REF/src/caffe/cpm/layers/imresize_layer.cu"
 NM="$REF/src/caffe/cpm/layers/nms_layer.cu"
+RF="$REF/src/rtpose/renderFunctions.cu"
 
 cut_range() {  # file first last expected-first-line-regex expected-last-line-regex output
   local f="$1" a="$2" b="$3" ra="$4" rb="$5" o="$6"
@@ -27,6 +28,8 @@ cut_range "$RT" 1383 1416 'FLAGS_write_json.empty' '^        }' rtpose_1383_1416
 cut_range "$IM" 8 18 '^template <typename Dtype>' '^}' imresize_8_18.inc
 cut_range "$IM" 98 155 '^template <typename Dtype>' '^}' imresize_98_155.inc
 cut_range "$NM" 14 113 '^template <typename Dtype>' '^}' nms_14_113.inc
+cut_range "$RF" 4 329 '^#define numThreadsPerBlock_1d 32' '^}' render_4_329.inc       # macros, colour maps, MPI kernels
+cut_range "$RF" 394 975 '^__global__ void render_pose_coco_parts' '^}' render_394_975.inc  # COCO kernels (pose, heat maps, PAFs)
 
 CXX="${CXX:-g++}"
 # -ffp-contract=off and no -ffast-math: the floating point of the C++ source, nothing else

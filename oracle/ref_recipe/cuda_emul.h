@@ -16,6 +16,10 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+using std::isnan;  // CUDA puts ::isnan in the global namespace
+inline float __saturatef(float v) { return v != v ? 0.f : (v < 0.f ? 0.f : (v > 1.f ? 1.f : v)); }  // clamp to [0,1], NaN -> 0 (CUDA math API)
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
 namespace cuda_emul {
 inline thread_local dim3 t_idx, b_idx, b_dim, g_dim;
 inline thread_local int phase = 1;

@@ -11,6 +11,7 @@
 //   rtpose.cpp:1383-1416   the --write_json block of displayFrame
 //   imresize_layer.cu:8-18, 98-155   cubic_interpolation, imresize_cubic_kernel
 //   nms_layer.cu:14-113              nms_register_kernel, writeResultKernel
+//   renderFunctions.cu:4-329, 394-975   the render kernels (pose overlay, heat-map and PAF views; MPI and COCO) with their colour maps
 // modelDescriptor.cpp / modelDescriptorFactory.cpp are compiled as they are (own translation units).
 // The launch sequences of ImResizeLayer::Forward_gpu (imresize_layer.cu:158-186) and NmsLayer::Forward_gpu
 // (nms_layer.cu:117-184, thrust::exclusive_scan = a serial exclusive prefix sum) are restated below: they are
@@ -85,6 +86,15 @@ namespace caffe {
 #include "gen/nms_14_113.inc"
 inline int updiv(int a, int b) { return (a + b - 1) / b; }  // caffe/cpm/util/math_functions.hpp
 }  // namespace caffe
+
+// renderFunctions.cu: the kernels as host C++ (one barrier each, pre-barrier part idempotent: two-phase emulation).  The host
+// wrappers render_mpi_parts / render_coco_parts / render_coco_aff (:331-389, :978-1080) are <<<>>> launches and are restated in
+// ref_render below — INCLUDING their swapped launch arguments (<<<threadsPerBlock, numBlocks>>>: a 32x32 grid of blocks of
+// updiv(w,32) x updiv(h,32) threads, which covers the same pixels).
+namespace refrender {
+#include "gen/render_4_329.inc"
+#include "gen/render_394_975.inc"
+}  // namespace refrender
 
 namespace {
 std::string g_err;
@@ -207,6 +217,67 @@ int ref_nms(const float* bottom, int height, int width, int num_parts, int max_p
       cuda_emul::emu_launch(dim3(caffe::updiv(offset, 256)), dim3(256), 2,
                             [&] { caffe::writeResultKernel<float>(offset, w_pointer1, src, dst, width, max_peaks); });
     }
+    return 0;
+  });
+}
+
+// render() of rtpose.cpp:270-299 on one frame, between the producer's canvas (process_and_pad_image(.., normalize = 0), :349) and the
+// post-processing thread's float -> u8 conversion (:1287-1296).  `heatmaps` = the resized map [C][net_h][net_w] (only read for part != 0).
+int ref_render(int model, const unsigned char* in_bgr, int w, int h, int net_w, int net_h, const float* heatmaps, const float* poses,
+               int num_people, int part_to_show, int googly, unsigned char* out_bgr) {
+  return guarded([&] {
+    using namespace refrender;
+    std::vector<float> canvas((size_t)w * h * 3);
+    {
+      cv::Mat m;
+      m.cols = w; m.rows = h; m.data = const_cast<unsigned char*>(in_bgr);
+      process_and_pad_image(canvas.data(), m, w, h, false);
+    }
+    std::vector<float> pose_copy(poses, poses + (size_t)std::max(1, num_people) * (model == 0 ? 18 : 15) * 3);
+    float* hm = const_cast<float*>(heatmaps);
+    const dim3 threadsPerBlock(numThreadsPerBlock_1d, numThreadsPerBlock_1d);
+    const dim3 numBlocks(caffe::updiv(w, threadsPerBlock.x), caffe::updiv(h, threadsPerBlock.y));
+    const float ratio_to_origin = (float)h / (float)net_h;
+    float* cv = canvas.data();
+    float* ps = pose_copy.data();
+    const int boxsize = 368;
+    if (model != 0) {  // render_mpi_parts :331-389
+      const float threshold = 0.0;
+      if (part_to_show == 0) {
+        if (num_people != 0)
+          cuda_emul::emu_launch(threadsPerBlock, numBlocks, 2, [&] { render_pose_29parts(cv, w, h, ratio_to_origin, ps, boxsize, num_people, threshold); });
+      } else if (part_to_show > 0) {
+        cuda_emul::emu_launch(threadsPerBlock, numBlocks, 2, [&] { render_pose_29parts_heatmap(cv, w, h, net_w, net_h, hm, num_people, part_to_show - 1); });
+      }
+    } else if (part_to_show - 1 <= 18) {  // render_coco_parts :978-1036
+      const float threshold = 0.01;
+      const int NUM_PARTS = 18;
+      if (part_to_show == 0) {
+        if (num_people != 0)
+          cuda_emul::emu_launch(threadsPerBlock, numBlocks, 2,
+                                [&] { render_pose_coco_parts(cv, w, h, ratio_to_origin, ps, boxsize, num_people, threshold, googly != 0); });
+      } else if (part_to_show > 0 && part_to_show < 58) {
+        if (part_to_show - 1 == NUM_PARTS)
+          cuda_emul::emu_launch(threadsPerBlock, numBlocks, 2, [&] { render_pose_coco_heatmap2(cv, w, h, net_w, net_h, hm, num_people, 0); });
+        else
+          cuda_emul::emu_launch(threadsPerBlock, numBlocks, 2, [&] { render_pose_coco_heatmap(cv, w, h, net_w, net_h, hm, num_people, part_to_show - 1); });
+      }
+    } else {  // rtpose.cpp:286-297 -> render_coco_aff :1038-1080
+      int aff_part = ((part_to_show - 1) - 18 - 1) * 2;
+      int num_parts_accum = 1;
+      if (aff_part == 0) num_parts_accum = 19;
+      else aff_part = aff_part - 2;
+      aff_part += 1 + 18;
+      cuda_emul::emu_launch(threadsPerBlock, numBlocks, 2, [&] { render_pose_coco_affinity(cv, w, h, net_w, net_h, hm, num_parts_accum, num_people, aff_part); });
+    }
+    const int offset = w * h;
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+          int value = int(canvas[(size_t)c * offset + i * w + j] + 0.5);
+          value = value < 0 ? 0 : (value > 255 ? 255 : value);
+          out_bgr[3 * (i * w + j) + c] = (unsigned char)(value);
+        }
     return 0;
   });
 }

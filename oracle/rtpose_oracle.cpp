@@ -981,3 +981,204 @@ ORC_API int orc_render_pose(int model, const unsigned char* in_bgr, int w, int h
     }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The --part_to_show views of render() (rtpose.cpp:270-299): a heat-map channel, all part maps at once, or PAF
+// channels, blended over the display frame.  renderFunctions.cu:12-120 (colour maps, cubic), :242-329 (MPI heat map),
+// :638-724 (COCO heat map), :726-836 (COCO all parts), :838-975 (COCO PAFs); dispatch :331-389, :978-1080.
+// `maps` = the net-resolution maps the Nms layer reads (resized_map), [C][net_h][net_w].  PINNED on the reference's own
+// kernels (tests/test_ref_pin.py::test_views_bit_equal).
+// ---------------------------------------------------------------------------------------------------------------
+namespace view {
+// jet-like map of renderFunctions.cu:12-43 (c = {first, second, third} as the kernels index it)
+static void jet(float* c, float v, float vmin, float vmax) {
+  c[0] = c[1] = c[2] = 255;
+  float dv;
+  if (v < vmin) v = vmin;
+  if (v > vmax) v = vmax;
+  dv = vmax - vmin;
+  if (v < (vmin + 0.125 * dv)) {
+    c[0] = 256 * (0.5 + (v * 4));
+    c[1] = c[2] = 0;
+  } else if (v < (vmin + 0.375 * dv)) {
+    c[0] = 255;
+    c[1] = 256 * (v - 0.125) * 4;
+    c[2] = 0;
+  } else if (v < (vmin + 0.625 * dv)) {
+    c[0] = 256 * (-4 * v + 2.5);
+    c[1] = 255;
+    c[2] = 256 * (4 * (v - 0.375));
+  } else if (v < (vmin + 0.875 * dv)) {
+    c[0] = 0;
+    c[1] = 256 * (-4 * v + 3.5);
+    c[2] = 255;
+  } else {
+    c[0] = 0;
+    c[1] = 0;
+    c[2] = 256 * (-4 * v + 4.5);
+  }
+}
+// colour wheel of renderFunctions.cu:45-92 (55 steps: 15 + 6 + 4 + 11 + 13 + 6)
+static void wheel(float* c, float v, float vmin, float vmax) {
+  c[0] = c[1] = c[2] = 255;
+  if (v < vmin) v = vmin;
+  if (v > vmax) v = vmax;
+  v = 55 * v;
+  const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
+  if (v < RY) {
+    c[0] = 255; c[1] = 255 * (v / (RY)); c[2] = 0;
+  } else if (v < RY + YG) {
+    c[0] = 255 - 255 * ((v - RY) / (YG)); c[1] = 255; c[2] = 0;
+  } else if (v < RY + YG + GC) {
+    c[0] = 0; c[1] = 255; c[2] = 255 * ((v - RY - YG) / (GC));
+  } else if (v < RY + YG + GC + CB) {
+    c[0] = 0; c[1] = 255 - 255 * ((v - RY - YG - GC) / (CB)); c[2] = 255;
+  } else if (v < RY + YG + GC + CB + BM) {
+    c[0] = 255 * ((v - RY - YG - GC - CB) / (BM)); c[1] = 0; c[2] = 255;
+  } else if (v < RY + YG + GC + CB + BM + MR) {
+    c[0] = 255; c[1] = 0; c[2] = 255 - 255 * ((v - RY - YG - GC - CB - BM) / (MR));
+  } else {
+    c[0] = 255; c[1] = 0; c[2] = 0;
+  }
+}
+// direction -> hue, magnitude -> brightness (renderFunctions.cu:94-109)
+static void direction_colour(float* c, float x, float y) {
+  float rad = sqrt(x * x + y * y);
+  float a = atan2(-y, -x) / M_PI;
+  float fk = (a + 1) / 2.0;
+  if (std::isnan(fk)) fk = 0;
+  if (rad > 1) rad = 1;
+  wheel(c, fk, 0, 1);
+  c[0] = 255 * (rad * (c[0] / 255));
+  c[1] = 255 * (rad * (c[1] / 255));
+  c[2] = 255 * (rad * (c[2] / 255));
+}
+static float cubic(float v0, float v1, float v2, float v3, float dx) {  // renderFunctions.cu:111-120
+  float out;
+  out = (-0.5f * v0 + 1.5f * v1 - 1.5f * v2 + 0.5f * v3) * dx * dx * dx + (v0 - 2.5f * v1 + 2.0 * v2 - 0.5 * v3) * dx * dx + (-0.5f * v0 + 0.5f * v2) * dx + v1;
+  return out;
+}
+struct Tap {  // where a canvas pixel falls in a net-resolution plane
+  bool inside;
+  int xn[4], yn[4];
+  float dx, dy;
+};
+static Tap locate(int x, int y, int w_canvas, int h_canvas, int w_net, int h_net) {
+  Tap t;
+  const float h_inv = (float)h_net / (float)h_canvas;
+  const float w_inv = (float)w_net / (float)w_canvas;
+  const float x_on_box = w_inv * x + (0.5 * w_inv - 0.5);
+  const float y_on_box = h_inv * y + (0.5 * h_inv - 0.5);
+  t.inside = x_on_box >= 0 && x_on_box < w_net && y_on_box >= 0 && y_on_box < h_net;
+  t.xn[1] = int(x_on_box + 1e-5);
+  t.xn[1] = (t.xn[1] < 0) ? 0 : t.xn[1];
+  t.xn[0] = (t.xn[1] - 1 < 0) ? t.xn[1] : (t.xn[1] - 1);
+  t.xn[2] = (t.xn[1] + 1 >= w_net) ? (w_net - 1) : (t.xn[1] + 1);
+  t.xn[3] = (t.xn[2] + 1 >= w_net) ? (w_net - 1) : (t.xn[2] + 1);
+  t.dx = x_on_box - t.xn[1];
+  t.yn[1] = int(y_on_box + 1e-5);
+  t.yn[1] = (t.yn[1] < 0) ? 0 : t.yn[1];
+  t.yn[0] = (t.yn[1] - 1 < 0) ? t.yn[1] : (t.yn[1] - 1);
+  t.yn[2] = (t.yn[1] + 1 >= h_net) ? (h_net - 1) : (t.yn[1] + 1);
+  t.yn[3] = (t.yn[2] + 1 >= h_net) ? (h_net - 1) : (t.yn[2] + 1);
+  t.dy = y_on_box - t.yn[1];
+  return t;
+}
+static float bicubic(const float* plane, int w_net, const Tap& t) {
+  float row[4];
+  for (int i = 0; i < 4; i++)
+    row[i] = cubic(plane[t.yn[i] * w_net + t.xn[0]], plane[t.yn[i] * w_net + t.xn[1]], plane[t.yn[i] * w_net + t.xn[2]], plane[t.yn[i] * w_net + t.xn[3]], t.dx);
+  return cubic(row[0], row[1], row[2], row[3], t.dy);
+}
+static float bilinear(const float* plane, int w_net, const Tap& t) {  // the 2x2 blend of render_pose_coco_affinity (:892-914)
+  const float a = plane[t.yn[1] * w_net + t.xn[1]], b = plane[t.yn[1] * w_net + t.xn[2]];
+  const float c = plane[t.yn[2] * w_net + t.xn[1]], d = plane[t.yn[2] * w_net + t.xn[2]];
+  return (1 - t.dx) * (1 - t.dy) * a + (t.dx) * (1 - t.dy) * b + (1 - t.dx) * (t.dy) * c + (t.dx) * (t.dy) * d;
+}
+}  // namespace view
+
+ORC_API int orc_render_view(int model, const unsigned char* in_bgr, int w, int h, int net_w, int net_h, const float* maps, int part_to_show,
+                            unsigned char* out_bgr) {
+  using namespace view;
+  if (part_to_show <= 0) return -1;
+  const long plane = (long)net_w * net_h;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float b = in_bgr[(y * w + x) * 3], g = in_bgr[(y * w + x) * 3 + 1], r = in_bgr[(y * w + x) * 3 + 2];
+      const Tap t = locate(x, y, w, h, net_w, net_h);
+      if (model != 0) {  // render_pose_29parts_heatmap (:242-329), part = part_to_show - 1
+        const int part = part_to_show - 1;
+        float value = (part == 15 - 1) ? 1 : 0;
+        if (t.inside) value = bicubic(maps + part * plane, net_w, t);
+        float c[3];
+        if (part < 16) jet(c, value, 0, 1);
+        else jet(c, value, -1, 1);
+        b = 0.5 * b + 0.5 * c[0];
+        g = 0.5 * g + 0.5 * c[1];
+        r = 0.5 * r + 0.5 * c[2];
+      } else if (part_to_show - 1 == 18) {  // render_pose_coco_heatmap2 (:726-836): all 18 part maps, nearest sample
+        float c[3] = {0, 0, 0};
+        for (int part = 0; part < 18; part++)
+          if (t.inside) {
+            const float value = maps[part * plane + t.yn[1] * net_w + t.xn[1]];
+            c[0] += value * kRenderColorCoco[(part % 18) * 3 + 0];
+            c[1] += value * kRenderColorCoco[(part % 18) * 3 + 1];
+            c[2] += value * kRenderColorCoco[(part % 18) * 3 + 2];
+          }
+        const float alpha = 0.7;
+        b = (1 - alpha) * b + alpha * c[2];
+        g = (1 - alpha) * g + alpha * c[1];
+        r = (1 - alpha) * r + alpha * c[0];
+      } else if (part_to_show - 1 <= 18) {  // render_pose_coco_heatmap (:638-724)
+        const int part = part_to_show - 1;
+        float value = (part == 18 - 1) ? 1 : 0;
+        if (t.inside) value = bicubic(maps + part * plane, net_w, t);
+        float c[3];
+        if (part < 18 + 1) jet(c, value, 0, 1);
+        else jet(c, value, -1, 1);
+        const float alpha = 0.7;
+        b = (1 - alpha) * b + alpha * c[2];
+        g = (1 - alpha) * g + alpha * c[1];
+        r = (1 - alpha) * r + alpha * c[0];
+      } else {  // rtpose.cpp:286-297 -> render_pose_coco_affinity (:838-975)
+        int aff_part = ((part_to_show - 1) - 18 - 1) * 2;
+        int num_parts_accum = 1;
+        if (aff_part == 0) num_parts_accum = 19;
+        else aff_part = aff_part - 2;
+        aff_part += 1 + 18;
+        float c[3] = {0, 0, 0};
+        for (int part = aff_part; part < aff_part + num_parts_accum * 2; part += 2)
+          if (t.inside) {
+            float value, value2;
+            if (num_parts_accum == 1) {
+              value = bilinear(maps + part * plane, net_w, t);
+              value2 = bilinear(maps + (part + 1) * plane, net_w, t);
+            } else {
+              value = maps[part * plane + t.yn[1] * net_w + t.xn[1]];
+              value2 = maps[(part + 1) * plane + t.yn[1] * net_w + t.xn[1]];
+            }
+            float c2[3];
+            direction_colour(c2, value, value2);
+            c[0] += c2[0];
+            c[1] += c2[1];
+            c[2] += c2[2];
+          }
+        if (c[0] > 255) c[0] = 255;
+        if (c[1] > 255) c[1] = 255;
+        if (c[2] > 255) c[2] = 255;
+        const float alpha = 0.7;
+        b = (1 - alpha) * b + alpha * c[2];
+        g = (1 - alpha) * g + alpha * c[1];
+        r = (1 - alpha) * r + alpha * c[0];
+      }
+      const float v3[3] = {b, g, r};
+      for (int c = 0; c < 3; c++) {
+        int value = int(v3[c] + 0.5);
+        value = value < 0 ? 0 : (value > 255 ? 255 : value);
+        out_bgr[(y * w + x) * 3 + c] = (unsigned char)value;
+      }
+    }
+  return 0;
+}
+

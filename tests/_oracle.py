@@ -124,6 +124,17 @@ def render_pose(model, bgr, joints, num_people, googly=0):
     return out
 
 
+def render_view(model, bgr, maps, part_to_show):
+    """the --part_to_show views of render() (heat map / all parts / PAFs) over a u8 BGR HWC image; maps [C][net_h][net_w]"""
+    img = np.ascontiguousarray(bgr, np.uint8)
+    m = np.ascontiguousarray(maps, np.float32)
+    out = np.empty_like(img)
+    rc = lib().orc_render_view(model, img.ctypes.data_as(C.POINTER(C.c_ubyte)), img.shape[1], img.shape[0], m.shape[2], m.shape[1], _f(m),
+                               int(part_to_show), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert rc == 0
+    return out
+
+
 def write_json(joints, num_people, num_parts, frame_scale):
     buf = C.create_string_buffer(1 << 20)
     j = np.ascontiguousarray(joints, np.float32)

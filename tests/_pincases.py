@@ -107,3 +107,48 @@ def pad_cases():
         for normalize in (0, 1):
             out.append((img, tw, th, normalize))
     return out
+
+
+def blocky_image(rs, w, h):
+    """display image made of 8x8 colour blocks (compresses well in the golden fixture, unlike per-pixel noise)"""
+    small = rs.randint(0, 256, size=(h // 8 + 1, w // 8 + 1, 3)).astype(np.uint8)
+    return np.ascontiguousarray(np.repeat(np.repeat(small, 8, axis=0), 8, axis=1)[:h, :w])
+
+
+def render_cases():
+    """(name, model, display image u8 [h][w][3], joints [n][parts][3] in display coordinates, n, googly): people of every size class
+    of render_pose_coco_parts (scale factor 0.33 .. 1), missing parts, joints outside the image, overlapping people."""
+    out = []
+    for name, model, w, h, n, seed, googly in (("coco", 0, 640, 360, 6, 31, 0), ("coco_googly", 0, 640, 360, 4, 32, 1), ("coco_odd", 0, 333, 201, 3, 33, 0),
+                                               ("mpi", 1, 640, 360, 5, 34, 0), ("coco_none", 0, 320, 180, 0, 35, 0)):
+        rs = np.random.RandomState(seed)
+        img = blocky_image(rs, w, h)
+        pose = _synth.COCO_POSE if model == 0 else _synth.MPI_POSE
+        parts = DIMS[model][0]
+        j = np.zeros((max(n, 1), parts, 3), np.float32)
+        for p in range(n):
+            size = (0.12, 0.3, 0.55, 0.9, 1.3, 0.2)[p % 6] * h       # small (scale clamp 0.33) .. larger than the 200 px threshold
+            cx, cy = rs.uniform(0.1, 0.9) * w, rs.uniform(-0.1, 0.5) * h
+            for k, (ux, uy) in pose.items():
+                j[p, k] = (cx + (ux - 0.5) * size * 0.6 + rs.uniform(-2, 2), cy + uy * size + rs.uniform(-2, 2), rs.uniform(0.05, 1.0))
+            for k in rs.choice(parts, size=3, replace=False):          # parts that were not found
+                j[p, k] = (0.0, 0.0, 0.0)
+        out.append((name, model, img, j[:n].copy() if n else j[:0].copy(), n, googly))
+    return out
+
+
+def view_cases(tables):
+    """(name, model, display image, net-resolution maps [C][net_h][net_w], part_to_show values).  Maps = ImResize of planted people
+    plus noise (values beyond [0,1] and [-1,1] exercise the colour-map clamps); canvases that are not multiples of the net size."""
+    import _oracle as orc
+    out = []
+    for name, model, w, h, net_w, net_h, seed, parts in (("coco", 0, 320, 180, 160, 96, 41, (1, 7, 18, 19, 20, 21, 30, 39)),
+                                                         ("coco_odd", 0, 333, 201, 160, 96, 42, (2, 19, 20, 25)),
+                                                         ("mpi", 1, 320, 180, 128, 96, 43, (1, 15, 16, 17, 44))):
+        rs = np.random.RandomState(seed)
+        img = blocky_image(rs, w, h)
+        C = DIMS[model][2]
+        low = _synth.people_lowres(model, tables[model], 3, net_h // 8, net_w // 8, seed=seed)[0] + 0.6 * _synth.smooth_field(C, net_h // 8, net_w // 8, seed=seed + 1)[None]
+        maps = orc.imresize(np.ascontiguousarray(low, np.float32), net_w, net_h, 1.0, 0.3)[0]
+        out.append((name, model, img, maps, parts))
+    return out

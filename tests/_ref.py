@@ -78,6 +78,20 @@ def connect(model, resized, peaks, max_peaks, net_w, net_h, disp_w, disp_h, thr,
     return cnt, joints
 
 
+def render(model, bgr, joints, num_people, net_w, net_h, part_to_show=0, googly=0, heatmaps=None):
+    """render() of rtpose.cpp:270-299 on one u8 BGR HWC display image (renderFunctions.cu kernels on the host)."""
+    img = np.ascontiguousarray(bgr, np.uint8)
+    j = np.ascontiguousarray(joints, np.float32).reshape(-1)
+    if j.size == 0:
+        j = np.zeros(3, np.float32)
+    hm = None if heatmaps is None else np.ascontiguousarray(heatmaps, np.float32)
+    out = np.empty_like(img)
+    _chk(lib().ref_render(model, img.ctypes.data_as(C.POINTER(C.c_ubyte)), img.shape[1], img.shape[0], net_w, net_h,
+                          _f(hm) if hm is not None else None, _f(j), int(num_people), int(part_to_show), int(googly),
+                          out.ctypes.data_as(C.POINTER(C.c_ubyte))))
+    return out
+
+
 def write_json(tmpdir, joints, num_people, model, frame_scale, frame_number=7, image_path=None):
     j = np.ascontiguousarray(joints, np.float32).reshape(-1)
     if j.size == 0:

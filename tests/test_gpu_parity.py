@@ -550,6 +550,30 @@ def test_rendered_frame_matches_oracle(model, W, H):
     e.close()
 
 
+def test_part_to_show_view_in_the_pipeline_matches_oracle():
+    """rtp_config.render = 1 + part_to_show: the frame rtp_collect_rendered returns is the oracle's view (itself pinned on the
+    reference's render kernels) of THAT frame's resized map — which the pipeline materialises only for this mode."""
+    import caffe_rtpose_amd as r
+    W, H, dw, dh = 320, 176, 640, 360
+    for part in (3, 19, 22):
+        e = _engine(model=0, net_w=W, net_h=H, disp_w=dw, disp_h=dh, frames_in_flight=2, render=1 + part)
+        img = r.synth_frame(800, 600, 1, seed=13)
+        x, disp, _ = r.preprocess_frame(img, dw, dh, W, H, 1, 1.0, 0.3)
+        e.submit_frame(img, tag=5)
+        tag, n, joints, got = e.collect_rendered()
+        resized = e.forward_debug(x)["resized"]
+        want = orc.render_view(0, disp, resized, part)
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        if part <= 19:
+            assert d.max() == 0, f"part_to_show {part}: {int((d > 0).any(-1).sum())} pixels differ"
+        else:   # PAF view: atan2 (ocml vs glibc)
+            assert d.max() <= 1 and (d > 0).any(-1).mean() < 1e-3
+        assert (got != disp).any()
+        e.close()
+    with pytest.raises(r.RtpError):
+        _engine(model=0, net_w=W, net_h=H, render=1 + 40)
+
+
 # ------------------------------------------------------------------------------------------
 # execution modes: the captured launch plan (hipGraph replay, default) == eager launches
 # ------------------------------------------------------------------------------------------

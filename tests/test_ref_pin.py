@@ -85,3 +85,28 @@ def test_json_bytes_equal(tmp_path):
         assert orc.write_json(joints if n else np.zeros((1, parts, 3), np.float32), n, parts, float(scale)) == ref_bytes
     name, _ = _ref.write_json(tmp_path, np.zeros((1, 18, 3), np.float32), 0, 0, 1.0, frame_number=0, image_path="/data/imgs/COCO_val_0001.jpg")
     assert name == "COCO_val_0001.json"       # <stem>.json for --image_dir (rtpose.cpp:1390-1393)
+
+
+def test_pose_overlay_bit_equal():
+    """orc_render_pose == render_pose_coco_parts / render_pose_29parts of renderFunctions.cu (run on the host, with the reference's
+    swapped <<<threadsPerBlock, numBlocks>>> launch shape) between the producer's float canvas and the post-processing thread's
+    float -> u8 conversion: identical u8 frames (both sides evaluate atan2f / sinf / cosf with the same libm here)."""
+    for name, model, img, joints, n, googly in pc.render_cases():
+        want = _ref.render(model, img, joints, n, 656, 368, part_to_show=0, googly=googly)
+        got = orc.render_pose(model, img, joints, n, googly)
+        assert np.array_equal(got, want), f"{name}: {int((got != want).any(-1).sum())} pixels differ"
+        if n:
+            assert (want != img).any(), name   # something was drawn
+        else:
+            assert np.array_equal(want, img)
+
+
+def test_views_bit_equal(tables):
+    """orc_render_view == render_pose_coco_heatmap / _heatmap2 / _affinity / render_pose_29parts_heatmap behind the dispatch of
+    render() (rtpose.cpp:270-299) for single parts, the last part (initial value 1), all parts, all PAFs, single PAF pairs."""
+    for name, model, img, maps, parts in pc.view_cases(tables):
+        for part in parts:
+            want = _ref.render(model, img, np.zeros((1, pc.DIMS[model][0], 3), np.float32), 0, maps.shape[2], maps.shape[1], part_to_show=part, heatmaps=maps)
+            got = orc.render_view(model, img, maps, part)
+            assert np.array_equal(got, want), f"{name} part_to_show {part}: {int((got != want).any(-1).sum())} pixels differ"
+            assert (want != img).any(), (name, part)

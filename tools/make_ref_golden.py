@@ -37,6 +37,13 @@ with tempfile.TemporaryDirectory() as d:
         out[f"json_{i}"] = np.frombuffer(_ref.write_json(d, joints, n, model, float(scale), frame_number=i)[1], np.uint8)
 for i, (img, tw, th, normalize) in enumerate(pc.pad_cases()):
     out[f"pad_{i}_sha"] = np.frombuffer(pc.digest(_ref.process_and_pad_image(img, tw, th, normalize)).encode(), np.uint8)
+# renderer (renderFunctions.cu on the host): the u8 frames in full (8x8-block display images compress well)
+for name, model, img, joints, n, googly in pc.render_cases():
+    out[f"render_{name}"] = _ref.render(model, img, joints, n, 656, 368, part_to_show=0, googly=googly)
+for name, model, img, maps, parts in pc.view_cases(tables):
+    for part in parts:
+        out[f"view_{name}_{part}"] = _ref.render(model, img, np.zeros((1, pc.DIMS[model][0], 3), np.float32), 0, maps.shape[2], maps.shape[1],
+                                                 part_to_show=part, heatmaps=maps)
 path = os.path.join(ROOT, "tests", "golden", "ref_pin.npz")
 np.savez_compressed(path, **out)
 print(f"wrote {path}: {os.path.getsize(path)} bytes, {len(out)} arrays")
