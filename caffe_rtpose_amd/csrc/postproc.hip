@@ -349,13 +349,18 @@ __global__ __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
 // low-res rows the strip touches, then the column interpolation, accumulated over the scales in
 // scale order — the arithmetic of resize_kernel), then flagged exactly like nms_strip_kernel.
 #define NMSF_TROWS 8
+// The kernel is ALU-bound (828 workgroups per frame, ~10 % of the chip next to the convolutions), so nothing is evaluated per
+// item that is constant along a row or a column: loops run row by row (no integer division), the x-axis neighbour / fraction
+// of every column is tabulated once per scale (xt), the y-axis ones are uniform per row, the first scale assigns 0 + d instead
+// of a zero pass, and the final division is skipped for one scale (x / 1 == x).  Same operations on the same values.
+struct XTab { int xn1; float dx; };  // axis_nb's clamped integer position (before padding) and fraction of one output column
 __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, ResizeParams r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = p.W, H = p.H;
   float* out = (float*)lds_raw;                 // [strip_rows + 2][W]
   float* T = out + (p.strip_rows + 2) * W;      // [NMSF_TROWS][W]
+  XTab* xt = (XTab*)(T + NMSF_TROWS * W);       // [W]
   __shared__ int wave_cnt[4];
-  __shared__ int running;
   const int strip = blockIdx.x, part = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = strip * p.strip_rows;
@@ -363,9 +368,6 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
   const int ya = max(y0 - 1, 0), yb = min(y1, H - 1);  // rows held in LDS: ya..yb
   const int nrow = yb - ya + 1;
   const long plane = (long)r.h * r.w;
-  for (int i = tid; i < nrow * W; i += 256) out[i] = 0.f;
-  if (tid == 0) running = 0;
-  __syncthreads();
   for (int n = 0; n < r.num; ++n) {
     const ScaleGeo g = scale_geo(r, n);
     const float* sp = r.src + ((long)n * r.C + part) * plane;
@@ -376,20 +378,35 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
     const int rhi = nb[3];
     const int nt = rhi - rlo + 1;
     if (nt <= NMSF_TROWS) {
-      for (int i = tid; i < nt * W; i += 256) {
-        const int rr = i / W, x = i - rr * W;
-        int xn[4];
-        const float dx = axis_nb(x, g.offset_x, g.fx, g.ow, g.padw, xn);
-        const float* row = sp + (rlo + rr) * g.rw;
-        T[rr * W + x] = cubic_interp(row[xn[0]], row[xn[1]], row[xn[2]], row[xn[3]], dx);
+      for (int x = tid; x < W; x += 256) {  // axis_nb(x, ..) once per column
+        const float x_on = (x - g.offset_x) * g.fx;
+        int xn1 = (int)((double)x_on + 1e-5);
+        xn1 = (xn1 < 0) ? 0 : xn1;
+        xt[x].xn1 = xn1;
+        xt[x].dx = x_on - xn1;
       }
       __syncthreads();
-      for (int i = tid; i < nrow * W; i += 256) {
-        const int yy = i / W, x = i - yy * W;
+      for (int rr = 0; rr < nt; ++rr) {
+        const float* row = sp + (rlo + rr) * g.rw + g.padw;
+        float* trow = T + rr * W;
+        for (int x = tid; x < W; x += 256) {
+          const XTab e = xt[x];
+          const int x0 = (e.xn1 - 1 < 0) ? e.xn1 : (e.xn1 - 1);
+          const int x2 = (e.xn1 + 1 >= g.ow) ? (g.ow - 1) : (e.xn1 + 1);
+          const int x3 = (x2 + 1 >= g.ow) ? (g.ow - 1) : (x2 + 1);
+          trow[x] = cubic_interp(row[x0], row[e.xn1], row[x2], row[x3], e.dx);
+        }
+      }
+      __syncthreads();
+      for (int yy = 0; yy < nrow; ++yy) {
         int yn[4];
-        const float dy = axis_nb(ya + yy, g.offset_y, g.fy, g.oh, g.padh, yn);
-        const float d = cubic_interp(T[(yn[0] - rlo) * W + x], T[(yn[1] - rlo) * W + x], T[(yn[2] - rlo) * W + x], T[(yn[3] - rlo) * W + x], dy);
-        out[i] = out[i] + d;
+        const float dy = axis_nb(ya + yy, g.offset_y, g.fy, g.oh, g.padh, yn);  // uniform over the row
+        const float *t0 = T + (yn[0] - rlo) * W, *t1 = T + (yn[1] - rlo) * W, *t2 = T + (yn[2] - rlo) * W, *t3 = T + (yn[3] - rlo) * W;
+        float* orow = out + yy * W;
+        for (int x = tid; x < W; x += 256) {
+          const float d = cubic_interp(t0[x], t1[x], t2[x], t3[x], dy);
+          orow[x] = (n == 0 ? 0.f : orow[x]) + d;
+        }
       }
       __syncthreads();
     } else {  // a strip spanning more low-res rows than the table holds (not with net/8 maps): per pixel
@@ -404,13 +421,15 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
           const float* row = sp + yn[q] * g.rw;
           t[q] = cubic_interp(row[xn[0]], row[xn[1]], row[xn[2]], row[xn[3]], dx);
         }
-        out[i] = out[i] + cubic_interp(t[0], t[1], t[2], t[3], dy);
+        out[i] = (n == 0 ? 0.f : out[i]) + cubic_interp(t[0], t[1], t[2], t[3], dy);
       }
       __syncthreads();
     }
   }
-  for (int i = tid; i < nrow * W; i += 256) out[i] = out[i] / r.num;
-  __syncthreads();
+  if (r.num != 1) {
+    for (int i = tid; i < nrow * W; i += 256) out[i] = out[i] / r.num;
+    __syncthreads();
+  }
   const int npix = (y1 - y0) * W;
   const int pix0 = y0 * W;
   int* list = p.strip_list + ((long)part * p.nstrips + strip) * p.max_peaks;
@@ -423,16 +442,28 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
   const int gper = (ngroups + 3) / 4;
   const int g0 = wave * gper, g1 = min(g0 + gper, ngroups);
   int mine = 0;
-  for (int g = g0; g < g1; ++g) {
-    const int q = g * 64 + lane;
-    int f = 0;
-    if (q < npix) {
-      const int gq = pix0 + q;
-      f = nms_flag(s, gq % W, gq / W, W, H, p.threshold);
+  {
+    int q = g0 * 64 + lane;            // this lane's pixel of group g, as (x, y) without a division per group
+    int py = y0 + q / W, px = q % W;
+    const float thr = p.threshold;
+    for (int g = g0; g < g1; ++g) {
+      int f = 0;
+      if (q < npix && px > 0 && px < W - 1 && py > 0 && py < H - 1) {  // nms_register_kernel, nms_layer.cu:15-46
+        const float* c = s + py * W + px;
+        const float v = c[0];
+        if (v > thr) {
+          const float top = c[-W], bottom = c[W], left = c[-1], right = c[1];
+          const float tl = c[-W - 1], tr = c[-W + 1], bl = c[W - 1], br = c[W + 1];
+          if (v > top && v > bottom && v > left && v > right && v > tl && v > bl && v > br && v > tr) f = 1;
+        }
+      }
+      const unsigned long long bal = __ballot(f);
+      if (lane == 0) bals[g] = bal;
+      mine += __popcll(bal);
+      q += 64;
+      px += 64;
+      while (px >= W) { px -= W; ++py; }
     }
-    const unsigned long long bal = __ballot(f);
-    if (lane == 0) bals[g] = bal;
-    mine += __popcll(bal);
   }
   if (lane == 0) wave_cnt[wave] = mine;
   __syncthreads();
@@ -444,8 +475,7 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
     if (((bal >> lane) & 1) && ord < p.max_peaks) list[ord] = pix0 + g * 64 + lane;
     ord0 += __popcll(bal);
   }
-  if (tid == 0) running = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-  if (tid == 0) p.strip_count[part * p.nstrips + strip] = running;
+  if (tid == 0) p.strip_count[part * p.nstrips + strip] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
 // Write kernel: the 49 window values of every kept peak are evaluated on demand by all threads,
@@ -541,7 +571,7 @@ static hipError_t ensure_lds(size_t bytes) {
 }
 
 hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream) {
-  const size_t lds1 = (size_t)(p.strip_rows + 2 + NMSF_TROWS) * p.W * sizeof(float);
+  const size_t lds1 = (size_t)(p.strip_rows + 2 + NMSF_TROWS) * p.W * sizeof(float) + (size_t)p.W * sizeof(XTab);
   if (lds1 > 150 * 1024) return hipErrorInvalidValue;
   if (lds1 > 64 * 1024) {
     hipError_t e = ensure_lds<nms_fused_strip_kernel>(lds1);
@@ -626,12 +656,12 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, Res
   __shared__ ScaleGeo geo[RTP_MAX_SCALES];
   if (FUSED) fill_scale_geo(geo, r);
   if (FUSED && stage) {
-    const int per = r.num * (int)lplane;
-    for (int t = threadIdx.x; t < 2 * per; t += 256) {
-      const int which = t / per, rem = t - which * per;
-      const int n = rem / (int)lplane, o = rem - n * (int)lplane;
-      lmap[t] = r.src[((long)n * r.C + mapIdx[2 * k + which]) * lplane + o];
-    }
+    for (int which = 0; which < 2; ++which)          // plane by plane: no integer division per element
+      for (int n = 0; n < r.num; ++n) {
+        const float* src = r.src + ((long)n * r.C + mapIdx[2 * k + which]) * lplane;
+        float* dst = lmap + ((long)which * r.num + n) * lplane;
+        for (int o = threadIdx.x; o < (int)lplane; o += 256) dst[o] = src[o];
+      }
     __syncthreads();
   }
   const int num_inter = 10;

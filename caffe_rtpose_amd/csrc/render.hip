@@ -21,7 +21,7 @@ __constant__ int kRLimbCoco[17 * 2] = {1, 2, 1, 5, 2, 3, 3, 4, 5, 6, 6, 7, 1, 8,
 __constant__ int kRLimbMpi[9 * 2] = {0, 1, 2, 3, 3, 4, 5, 6, 6, 7, 8, 9, 9, 10, 11, 12, 12, 13};
 
 // table layout (floats): [0] = number of people; person p at 8 + p * RTAB_PERSON:
-//   [0..3] box min x, min y, max x, max y   [4] scale   [8 + l*6 ..] limb l: valid, x_p, y_p, sine, cosine, a_sqrt
+//   [0..3] box min x, min y, max x, max y   [4] scale   [8 + l*6 ..] limb l: valid, mid_x, mid_y, dir_s, dir_c, half_len2
 #define RTAB_PERSON (8 + 17 * 6)
 
 __global__ __launch_bounds__(128) void render_prep_kernel(RenderParams p) {
@@ -63,10 +63,10 @@ __global__ __launch_bounds__(128) void render_prep_kernel(RenderParams p) {
       const float x_a = ps[a * 3], x_b = ps[b * 3], y_a = ps[a * 3 + 1], y_b = ps[b * 3 + 1];
       float* o = t + 8 + l * 6;
       if (ps[a * 3 + 2] > threshold && ps[b * 3 + 2] > threshold) {
-        const float x_p = (x_a + x_b) / 2, y_p = (y_a + y_b) / 2;
+        const float mid_x = (x_a + x_b) / 2, mid_y = (y_a + y_b) / 2;
         const float angle = atan2f(y_b - y_a, x_b - x_a);
-        o[0] = 1.f; o[1] = x_p; o[2] = y_p; o[3] = sinf(angle); o[4] = cosf(angle);
-        o[5] = (x_a - x_p) * (x_a - x_p) + (y_a - y_p) * (y_a - y_p);
+        o[0] = 1.f; o[1] = mid_x; o[2] = mid_y; o[3] = sinf(angle); o[4] = cosf(angle);
+        o[5] = (x_a - mid_x) * (x_a - mid_x) + (y_a - mid_y) * (y_a - mid_y);
       } else {
         o[0] = 0.f;
       }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void render_pose_kernel(RenderParams p) {
   if (coco) {
     const float threshold = 0.01f;
     const float radius = 2 * p.h / 200.0f;
-    const float stickwidth = p.h / 120.0f;
+    const float limb_width = p.h / 120.0f;
     for (int q = 0; q < n; q++) {
       const float* t = p.tab + 8 + (size_t)q * RTAB_PERSON;
       if (x > t[2] || x < t[0] || y > t[3] || y < t[1]) continue;
@@ -94,42 +94,42 @@ __global__ __launch_bounds__(256) void render_pose_kernel(RenderParams p) {
       for (int l = 0; l < 17; l++) {
         const float* o = t + 8 + l * 6;
         if (o[0] == 0.f) continue;
-        const float b_sqrt = sc * sc * stickwidth * stickwidth;
+        const float half_wid2 = sc * sc * limb_width * limb_width;
         const float alpha = 0.5;
-        const float x_p = o[1], y_p = o[2], sine = o[3], cosine = o[4], a_sqrt = o[5];
-        const float A = cosine * (x - x_p) + sine * (y - y_p);
-        const float B = sine * (x - x_p) - cosine * (y - y_p);
-        const float judge = A * A / a_sqrt + B * B / b_sqrt;
-        if (judge >= 0 && judge <= 1) {
+        const float mid_x = o[1], mid_y = o[2], dir_s = o[3], dir_c = o[4], half_len2 = o[5];
+        const float A = dir_c * (x - mid_x) + dir_s * (y - mid_y);
+        const float B = dir_s * (x - mid_x) - dir_c * (y - mid_y);
+        const float ellipse_lhs = A * A / half_len2 + B * B / half_wid2;
+        if (ellipse_lhs >= 0 && ellipse_lhs <= 1) {
           b = (1 - alpha) * b + alpha * kRColorCoco[l * 3 + 2];
           g = (1 - alpha) * g + alpha * kRColorCoco[l * 3 + 1];
           r = (1 - alpha) * r + alpha * kRColorCoco[l * 3 + 0];
         }
       }
       for (int i = 0; i < 18; i++) {
-        const float local_x = ps[i * 3], local_y = ps[i * 3 + 1], value = ps[i * 3 + 2];
+        const float jx = ps[i * 3], jy = ps[i * 3 + 1], value = ps[i * 3 + 2];
         if (value > threshold) {
-          const float dist2 = (x - local_x) * (x - local_x) + (y - local_y) * (y - local_y);
-          float minr2 = 0;
-          float maxr2 = sc * sc * radius * radius;
+          const float d2 = (x - jx) * (x - jx) + (y - jy) * (y - jy);
+          float ring_lo2 = 0;
+          float ring_hi2 = sc * sc * radius * radius;
           float alpha = 0.6;
           float cx = kRColorCoco[i * 3 + 0], cy = kRColorCoco[i * 3 + 1], cz = kRColorCoco[i * 3 + 2];
           if (p.googly && (i == 14 || i == 15)) {
-            maxr2 = sc * sc * 2.5 * 2.5 * radius * radius;
-            minr2 = sc * sc * (2.5 * radius - 2) * (2.5 * radius - 2);
+            ring_hi2 = sc * sc * 2.5 * 2.5 * radius * radius;
+            ring_lo2 = sc * sc * (2.5 * radius - 2) * (2.5 * radius - 2);
             alpha = 0.9;
             cx = 0; cy = 0; cz = 0;
-            if (dist2 <= maxr2) {
-              if (dist2 <= minr2) { cx = 255; cy = 255; cz = 255; }
-              if (dist2 <= minr2 * 0.6) {
-                const float dist3 = (x - 4 - local_x) * (x - 4 - local_x) + (y - local_y + 4) * (y - local_y + 4);
-                if (dist3 > 3.75 * 3.75) { cx = 0; cy = 0; cz = 0; }
+            if (d2 <= ring_hi2) {
+              if (d2 <= ring_lo2) { cx = 255; cy = 255; cz = 255; }
+              if (d2 <= ring_lo2 * 0.6) {
+                const float d2_pupil = (x - 4 - jx) * (x - 4 - jx) + (y - jy + 4) * (y - jy + 4);
+                if (d2_pupil > 3.75 * 3.75) { cx = 0; cy = 0; cz = 0; }
               }
               b = (1 - alpha) * b + alpha * cz;
               g = (1 - alpha) * g + alpha * cy;
               r = (1 - alpha) * r + alpha * cx;
             }
-          } else if (dist2 >= minr2 && dist2 <= maxr2) {
+          } else if (d2 >= ring_lo2 && d2 <= ring_hi2) {
             b = (1 - alpha) * b + alpha * cz;
             g = (1 - alpha) * g + alpha * cy;
             r = (1 - alpha) * r + alpha * cx;
@@ -140,27 +140,27 @@ __global__ __launch_bounds__(256) void render_pose_kernel(RenderParams p) {
   } else {
     const float threshold = 0.0f;
     const float radius = 3 * p.h / 200.0f;
-    const float stickwidth = p.h / 60.0f;
+    const float limb_width = p.h / 60.0f;
     for (int q = 0; q < n; q++) {
       const float* t = p.tab + 8 + (size_t)q * RTAB_PERSON;
       const float* ps = p.poses + (size_t)q * 15 * 3;
       for (int l = 0; l < 9; l++) {
         const float* o = t + 8 + l * 6;
         if (o[0] == 0.f) continue;
-        float b_sqrt = stickwidth * stickwidth;
+        float half_wid2 = limb_width * limb_width;
         const float alpha = 0.6;
-        const float x_p = o[1], y_p = o[2], sine = o[3], cosine = o[4];
-        float a_sqrt = o[5];
+        const float mid_x = o[1], mid_y = o[2], dir_s = o[3], dir_c = o[4];
+        float half_len2 = o[5];
         if (l == 0) {
-          a_sqrt *= 1.2;
-          b_sqrt = a_sqrt;
+          half_len2 *= 1.2;
+          half_wid2 = half_len2;
         }
-        const float A = cosine * (x - x_p) + sine * (y - y_p);
-        const float B = sine * (x - x_p) - cosine * (y - y_p);
-        const float judge = A * A / a_sqrt + B * B / b_sqrt;
+        const float A = dir_c * (x - mid_x) + dir_s * (y - mid_y);
+        const float B = dir_s * (x - mid_x) - dir_c * (y - mid_y);
+        const float ellipse_lhs = A * A / half_len2 + B * B / half_wid2;
         float minV = 0;
         if (l == 0) minV = 0.8;
-        if (judge >= minV && judge <= 1) {
+        if (ellipse_lhs >= minV && ellipse_lhs <= 1) {
           b = (1 - alpha) * b + alpha * kRColorMpi[l * 3 + 2];
           g = (1 - alpha) * g + alpha * kRColorMpi[l * 3 + 1];
           r = (1 - alpha) * r + alpha * kRColorMpi[l * 3];
