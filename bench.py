@@ -34,7 +34,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 PREC_NOTE = {
-    "mixed": "fp16 MFMA, fp32 accumulate; conv2_*..conv4_*, refinement stages 4-6 and all 1x1 layers run as hi+lo fp16 pairs (a_hi*W_hi + a_lo*W_hi + a_hi*W_lo): "
+    "mixed": "fp16 MFMA, fp32 accumulate; conv2_*..conv4_*, refinement stages 4-6 and all 1x1 layers also multiply the fp16 rounding errors of both operands "
+             "(a_hi*W_hi + a_lo*W_hi + a_hi*W_lo; the two corrections as MX-scaled fp8 MFMA chunks on the 3x3/7x7 layers, as fp16 passes on the 1x1 layers): "
              "final maps within 1e-3 of the fp32 reference (normalised to max 1), tests/test_precision.py",
     "fp16": "fp16 storage and MFMA everywhere, fp32 accumulate: final maps 2.0-2.6e-3 from the fp32 reference, OUTSIDE the +-1e-3 north-star tolerance",
     "f16x3": "every layer as hi+lo fp16 pairs in three MFMA passes: fp32-class accuracy",
@@ -126,9 +127,9 @@ def main():
     ap.add_argument("--num_scales", type=int, default=1)
     ap.add_argument("--scale_gap", type=float, default=0.3)
     ap.add_argument("--precision", default="mixed", choices=["mixed", "fp16", "f16x3", "fp32"],
-                    help="mixed (default) = fp16 MFMA with the error-dominant layers as hi/lo fp16 pairs in three passes: the fastest mode inside the "
+                    help="mixed (default) = fp16 MFMA with fp8 error-compensation chunks on the error-dominant layers: the fastest mode inside the "
                          "north-star tolerance (+-1e-3 on maps normalised to 1, tests/test_precision.py); fp16 = single-pass everywhere (2x outside it); "
-                         "f16x3 = every layer split; fp32 = exact-f32 MFMA")
+                         "f16x3 = every layer as three fp16 passes; fp32 = exact-f32 MFMA")
     ap.add_argument("--split_layers", default=None, help="override the split set of --precision mixed (rtp_config.split_layers syntax)")
     ap.add_argument("--in_flight", type=int, default=8)
     ap.add_argument("--batch_frames", type=int, default=2, help="frames whose conv stacks share one launch sequence (1 = the reference's one frame per Forward)")
@@ -243,7 +244,8 @@ def main():
         # dominant kernel: the paired 7x7 128->128 convolution (40 of the 92 layers, 50% of all FLOPs).  Average launch duration over
         # EVERY launch of that kernel symbol inside the timed, pipelined region (what rocprofv3 --stats averages), from in-kernel
         # wall-clock stamps (first workgroup start -> last workgroup end).  `achieved` counts ALGORITHMIC flops (2*Cout*Cin*k*k*H*W per
-        # image): a split-precision launch executes three MFMA passes for them, reported separately under `executed`.
+        # image): an error-compensated launch spends 2 (fp16 + fp8 chunks) or 3 (three fp16 passes) pass-times of the matrix pipe on
+        # them, reported separately under `executed` (pass-time equivalents: an fp8 chunk takes the time of the fp16 chunk it corrects).
         peak = 157.3e12 if args.precision == "fp32" else 2.5e15
         ms = dom_ms / max(dom_n, 1)
         achieved = dom_flops / (ms * 1e-3) if ms > 0 else 0.0
@@ -256,7 +258,7 @@ def main():
             roof["by_mfma_passes"] = {str(p): {"launches": n, "ms_per_launch": t / n, "algorithmic_tflops": dom_flops / (t / n * 1e-3) / 1e12,
                                                "executed_mfma_tflops": p * dom_flops / (t / n * 1e-3) / 1e12} for p, (t, n) in byp.items()}
             roof["executed"] = {"mfma_tflops": exec_flops / (dom_ms * 1e-3) / 1e12, "frac_of_peak": exec_flops / (dom_ms * 1e-3) / peak,
-                                "note": "MFMA flops actually issued (split-precision launches run 3 passes per algorithmic flop)"}
+                                "note": "matrix-pipe work actually issued, in fp16-pass equivalents (error-compensated launches: 2 or 3 passes per algorithmic flop)"}
         solo_ms, _ = eng.bench_dominant_conv(iters=200)   # the same kernel alone on the chip (no other frame sharing the CUs)
         roof["solo"] = {"ms_per_launch": solo_ms, "achieved": dom_flops / (solo_ms * 1e-3) / 1e12, "frac": dom_flops / (solo_ms * 1e-3) / peak}
         fps = m["fps"]

@@ -642,7 +642,7 @@ int build_plan(rtp_engine* e) {
     const Step& s = e->steps[si];
     if (s.type == 1 && e->convs[s.a].k == 7 && e->convs[s.a].cin == 128) { e->dominant_step = (int)si; break; }
   }
-  e->strip_rows = 8;
+  e->strip_rows = e->N > 1 ? 16 : 8;  // several scales: the row interpolations of a strip are the larger share, taller strips amortise them (+3 % frames/s at 3 scales)
   if (const char* sr = getenv("RTP_NMS_STRIP_ROWS")) { const int v = atoi(sr); if (v >= 2 && v <= 16) e->strip_rows = v; }  // experiments
   e->nstrips = (e->cfg.net_h + e->strip_rows - 1) / e->strip_rows;
   e->max_rows = e->num_limbs * e->max_peaks;

@@ -4,6 +4,8 @@ Post-processing (ImResize, Nms, connectLimbs*) is BIT-EXACT given identical inpu
 stack is floating point: tolerance stated per test (north_star: keypoints within +-1 px /
 +-1e-3 confidence).  /root/reference is never read here.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -640,3 +642,27 @@ def test_device_preprocess_equals_independent_opencv_restatement(geom):
     assert np.array_equal(disp, want_disp)
     assert np.array_equal(x, want_x)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------
+# experiment variants kept in the tree must keep producing the production bits
+# ------------------------------------------------------------------------------------------
+def test_ring_kernel_variants_are_bit_identical():
+    """RTP_RING_ILV=1 (interleaved A-fragment rows: DPP shifts instead of LDS re-reads, conv_ring.hip) and RTP_HALO_SHARED=0 (a
+    halo on both sides of every row) only change HOW operands reach the MFMAs: low-res maps, blobs and joints hash identically
+    to the default build (tools/ab_hash.py, separate processes: the switches are read once per process)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ab_hash.py")
+
+    def run(**env):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, tool, "--quick"], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l and not l.startswith("#")]
+
+    base = run()
+    assert len(base) == 2 and all("nan 0" in l for l in base)
+    assert run(RTP_RING_ILV="1") == base
+    assert run(RTP_HALO_SHARED="0") == base

@@ -14,8 +14,9 @@ import _synth  # noqa: E402
 
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("RTP_"))
 print(f"# [{tag}]")
+QUICK = "--quick" in sys.argv  # one plan per precision (the GPU test of the experiment variants)
 for prec_name, prec in (("fp16", r.PREC_FP16), ("mixed", r.PREC_MIXED)) + ((("f16x3", r.PREC_F16X3),) if "--all" in sys.argv else ()):
-    for (W, H, N, B) in ((656, 368, 1, 2), (656, 368, 3, 1)) + (((160, 96, 1, 1),) if "--all" in sys.argv else ()):
+    for (W, H, N, B) in ((656, 368, 1, 2),) + (() if QUICK else ((656, 368, 3, 1),)) + (((160, 96, 1, 1),) if "--all" in sys.argv else ()):
         e = r.Engine(r.Config(net_w=W, net_h=H, num_scales=N, scale_gap=0.15, precision=prec, frames_in_flight=2 * B, batch_frames=B))
         x = _synth.random_frame(N, H, W, seed=11)
         d = e.forward_debug(x)
