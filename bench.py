@@ -75,12 +75,14 @@ def cpu_baseline(eng, num_scales, model="coco", frames=3):
                       f"post-processing {tp / frames:.3f} s per frame, OpenMP fp32 (oracle/rtpose_oracle.cpp)"}
 
 
-def pmc_traffic(precision, batch_frames, num_scales, model):
+def pmc_traffic(precision, batch_frames, num_scales, model, suffix=""):
     """HBM bytes per dominant launch from the newest rocprofv3 PMC summary under profiles/ whose header names this
     configuration (tools/collect_profiles.sh writes them: one counter per pass).  FETCH_SIZE/WRITE_SIZE are KiB;
     FETCH_SIZE x2 per the guide's gfx950 correction.  None when no matching profile is committed."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dominant_conv_pmc*.txt")), reverse=True):
+        if path.endswith("_2q.txt") != (suffix == "_2q"):
+            continue
         try:
             lines = open(path).read().splitlines()
         except OSError:
@@ -235,30 +237,53 @@ def main():
     frames = device_frames(args.num_scales)
     m = measure(eng, lambda i, tag: eng.submit_device(frames[i % len(frames)].data_ptr(), tag=tag), args.steps, args.warmup, args.in_flight,
                 args.min_seconds, timing=True)
-    dom_ms, dom_n, dom_flops = eng.kernel_timing(-1)   # read (harvests the stamps of the timed pass)
+    pip_ms, pip_n, dom_flops = eng.kernel_timing(-1)   # read (harvests the stamps of the timed, pipelined pass)
+    pip_byp = eng.kernel_timing_by_passes()
+    # The same plan once more, ONE BATCH AT A TIME (submit batch_frames frames, collect them, repeat): no other frame's kernels are
+    # on the chip while a launch runs, so first-workgroup-start -> last-workgroup-end is that launch's own duration — the quantity
+    # a rocprofv3 kernel trace averages (the tracer serialises dispatches).  In the pipelined region launches of different frames
+    # overlap (a 1/8-resolution launch is 248 workgroups on 256 CUs, the next stream's kernel starts in its tail), so their spans
+    # stretch although the chip does MORE work per second: those spans are reported as `pipelined_span` only.
+    eng.kernel_timing(2)
+    nb = max(1, args.batch_frames)
+    for b in range(40):
+        for j in range(nb):
+            eng.submit_device(frames[(b * nb + j) % len(frames)].data_ptr(), tag=b * nb + j)
+        for j in range(nb):
+            eng.collect()
+    dom_ms, dom_n, dom_flops = eng.kernel_timing(-1)
     byp = eng.kernel_timing_by_passes()
     eng.kernel_timing(0)
     stage = eng.last_stage_ms()
 
     if rank == 0:
         # dominant kernel: the paired 7x7 128->128 convolution (40 of the 92 layers, 50% of all FLOPs).  Average launch duration over
-        # EVERY launch of that kernel symbol inside the timed, pipelined region (what rocprofv3 --stats averages), from in-kernel
-        # wall-clock stamps (first workgroup start -> last workgroup end).  `achieved` counts ALGORITHMIC flops (2*Cout*Cin*k*k*H*W per
-        # image): an error-compensated launch spends 2 (fp16 + fp8 chunks) or 3 (three fp16 passes) pass-times of the matrix pipe on
-        # them, reported separately under `executed` (pass-time equivalents: an fp8 chunk takes the time of the fp16 chunk it corrects).
+        # EVERY launch of that kernel shape (both instantiations: the plain fp16 one and the fp8-compensated one) inside whole frames,
+        # from in-kernel wall-clock stamps.  `achieved` counts ALGORITHMIC flops (2*Cout*Cin*k*k*H*W per image): an error-compensated
+        # launch spends 2 (fp16 + fp8 chunks) or 3 (three fp16 passes) pass-times of the matrix pipe on them, reported separately under
+        # `executed` (pass-time equivalents: an fp8 chunk takes the time of the fp16 chunk it corrects).
         peak = 157.3e12 if args.precision == "fp32" else 2.5e15
         ms = dom_ms / max(dom_n, 1)
         achieved = dom_flops / (ms * 1e-3) if ms > 0 else 0.0
         tr = pmc_traffic(args.precision, args.batch_frames, args.num_scales, args.model)
+        tr2 = pmc_traffic(args.precision, args.batch_frames, args.num_scales, args.model, "_2q")
         roof = {"bound": "mfma", "kernel": "conv_ring_kernel 7x7 128->128 (L1+L2 branch pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                "ms_per_launch": ms, "launches_timed": dom_n, "flops_per_launch": dom_flops}
+                "ms_per_launch": ms, "launches_timed": dom_n, "flops_per_launch": dom_flops,
+                "how": "in-kernel stamps over 40 batches processed one at a time (whole frames, no other frame's kernels on the chip): what a rocprofv3 kernel trace averages"}
+        if tr2:  # the fp8-compensated launches of the same shape read the q blocks and the fp8 weight chunks as well
+            roof["traffic_2q"] = tr2["bytes"]
+            roof["traffic_2q_source"] = tr2["source"]
         if byp:
             exec_flops = sum(p * n for p, (_, n) in byp.items()) * dom_flops
             roof["by_mfma_passes"] = {str(p): {"launches": n, "ms_per_launch": t / n, "algorithmic_tflops": dom_flops / (t / n * 1e-3) / 1e12,
                                                "executed_mfma_tflops": p * dom_flops / (t / n * 1e-3) / 1e12} for p, (t, n) in byp.items()}
             roof["executed"] = {"mfma_tflops": exec_flops / (dom_ms * 1e-3) / 1e12, "frac_of_peak": exec_flops / (dom_ms * 1e-3) / peak,
                                 "note": "matrix-pipe work actually issued, in fp16-pass equivalents (error-compensated launches: 2 or 3 passes per algorithmic flop)"}
+        if pip_n:
+            roof["pipelined_span"] = {"ms_per_launch": pip_ms / pip_n, "launches": pip_n,
+                                      "by_mfma_passes": {str(p): t / n for p, (t, n) in (pip_byp or {}).items()},
+                                      "note": "first-start -> last-end of the same launches inside the timed region, where kernels of up to 4 batches overlap on the chip"}
         solo_ms, _ = eng.bench_dominant_conv(iters=200)   # the same kernel alone on the chip (no other frame sharing the CUs)
         roof["solo"] = {"ms_per_launch": solo_ms, "achieved": dom_flops / (solo_ms * 1e-3) / 1e12, "frac": dom_flops / (solo_ms * 1e-3) / peak}
         fps = m["fps"]

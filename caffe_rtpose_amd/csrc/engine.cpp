@@ -640,7 +640,8 @@ int build_plan(rtp_engine* e) {
   e->dominant_step = -1;
   for (size_t si = 0; si < e->steps.size(); ++si) {
     const Step& s = e->steps[si];
-    if (s.type == 1 && e->convs[s.a].k == 7 && e->convs[s.a].cin == 128) { e->dominant_step = (int)si; break; }
+    static const char* dq = getenv("RTP_DOMINANT_Q");  // profiling: 1 = probe the first fp8-compensated launch of that shape instead (stage 4)
+    if (s.type == 1 && e->convs[s.a].k == 7 && e->convs[s.a].cin == 128 && (!(dq && dq[0] == '1') || e->convs[s.a].h8)) { e->dominant_step = (int)si; break; }
   }
   e->strip_rows = e->N > 1 ? 16 : 8;  // several scales: the row interpolations of a strip are the larger share, taller strips amortise them (+3 % frames/s at 3 scales)
   if (const char* sr = getenv("RTP_NMS_STRIP_ROWS")) { const int v = atoi(sr); if (v >= 2 && v <= 16) e->strip_rows = v; }  // experiments

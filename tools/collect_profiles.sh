@@ -12,6 +12,7 @@ tail -c 400 $O/bench_${P}_n1.json
 rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --precision $P --no_cpu_baseline --no_sub_results > $O/bench_${P}_n1_under_rocprof.json 2> /tmp/kt.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_${P}_n1_kernel_stats.csv
 python $R/tools/timeline.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) > $O/bench_${P}_n1_timeline.txt 2>&1
+[ "${2:-}" = nopmc ] && exit 0   # bench line + kernel stats only
 B=$(python -c "import json;print(json.loads([l for l in open('$O/bench_${P}_n1.json') if l.startswith('{')][-1])['config'].get('batch_frames', 2))" 2>/dev/null || echo 2)
 : > $O/dominant_conv_pmc_${P}_b$B.txt
 echo "# rocprofv3 --kernel-trace --pmc <group> -- python tools/prof_dominant.py $P 20 $B   (one group per pass)" >> $O/dominant_conv_pmc_${P}_b$B.txt
@@ -21,3 +22,13 @@ for grp in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT S
 done
 tail -3 /tmp/pmc.log >> $O/dominant_conv_pmc_${P}_b$B.txt
 cat $O/dominant_conv_pmc_${P}_b$B.txt | cut -c1-150
+if [ "$P" = mixed ]; then  # the same shape as an fp8-compensated launch (stages 4-6: most of the symbol's time in the mixed plan)
+  Q=$O/dominant_conv_pmc_${P}_b${B}_2q.txt
+  echo "# RTP_DOMINANT_Q=1 rocprofv3 --kernel-trace --pmc <group> -- python tools/prof_dominant.py $P 20 $B   (one group per pass; the fp8-compensated launch)" > $Q
+  for grp in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do
+    rm -rf /tmp/pmc; RTP_DOMINANT_Q=1 timeout 60 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc -- python $R/tools/prof_dominant.py $P 20 $B > /tmp/pmc.log 2>&1
+    python $R/tools/pmc_summary.py /tmp/pmc conv_ring >> $Q 2>&1 || echo "group '$grp' failed" >> $Q
+  done
+  tail -1 /tmp/pmc.log >> $Q
+  cat $Q | cut -c1-150
+fi
