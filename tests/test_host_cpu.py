@@ -397,3 +397,15 @@ def test_split_precision_plan_and_rule_syntax():
     assert " passes 2q " in dflt["conv3_2"] and " passes 2q " in dflt["Mconv3_stage6_L1"] and " passes 1 " in dflt["Mconv3_stage3_L1"]
     assert " passes 1 " in lines["conv3_1"]
     assert " passes 3aw/3aw " in lines["Mconv6_stage6_L1"]   # the fused 1x1 pair: passes of the first / second layer
+
+
+def test_eighth_resolution_launches_leave_cus_free():
+    """Shared row halo: a 46x82 image is 31 M-tiles of 128 (46 * 85 = 3910 GEMM rows), so at batch_frames = 2
+    every 1/8-resolution launch of the default plan is 248 workgroups — not 256, which would need every CU of the chip at once."""
+    import re
+    import caffe_rtpose_amd as r
+    steps = [ln for ln in r.plan_summary(r.Config(precision=r.PREC_MIXED, frames_in_flight=8, batch_frames=2)).splitlines() if ln.startswith("step")]
+    low = [ln for ln in steps if re.search(r"(conv4_|conv5_|Mconv)", ln)]
+    assert len(low) >= 40
+    for ln in low:
+        assert int(re.search(r"wgs (\d+)", ln).group(1)) == 248, ln
