@@ -406,6 +406,6 @@ def test_eighth_resolution_launches_leave_cus_free():
     import caffe_rtpose_amd as r
     steps = [ln for ln in r.plan_summary(r.Config(precision=r.PREC_MIXED, frames_in_flight=8, batch_frames=2)).splitlines() if ln.startswith("step")]
     low = [ln for ln in steps if re.search(r"(conv4_|conv5_|Mconv)", ln)]
-    assert len(low) >= 40
+    assert len(low) >= 38
     for ln in low:
         assert int(re.search(r"wgs (\d+)", ln).group(1)) == 248, ln
