@@ -443,10 +443,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       if (q >= TM) nb_[gi][q - TM] = *(const uint4*)(pb + (q - TM) * 32 * CHB + ((cl ^ bswz) * 16));
       else if constexpr (!ILV) na_[gi][q] = *(const uint4*)(pa + q * 32 * CHB + ((cl ^ aswz) * 16));
       else if constexpr (s == 0) na_[gi][q] = *a_ilv(q, 0, abuf_, cl);       // first tap of a strip: fresh rows
-      else if (q < TM - 1) na_[gi][q] = fa[gi][q + 1];                        // pixels TM*l + q + s + 1 = fragment q+1 of tap s
-      else na_[gi][q] = lanes_down1(fa[gi][0]);                              // pixels TM*(l+1) + s: fragment 0 of the lane above
+      else if (q < TM - 1) na_[gi][q] = fa[gi][q + 1];                        // tap s wants the pixels TM*l + q + s = fragment q+1 of tap s-1 (held in fa)
+      else na_[gi][q] = lanes_down1(fa[gi][0]);                              // TM*l + TM-1 + s = TM*(l+1) + s-1: tap s-1's fragment 0, one lane up
     };
-    // ILV: the one row the shift cannot supply (lanes 31 and 63 of fragment TM-1), all k-groups in one divergent region
+    // ILV: the one row the shift cannot supply (lanes 31 and 63 of fragment TM-1): exec-masked reads, see lds_read_lanes
     auto read_boundary_c = [&](auto s_tag, int abuf_) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
 #if ILV_EXP != 1
