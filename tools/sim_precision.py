@@ -93,7 +93,14 @@ def blk_exp(x, block):
     return s.expand(n, cp // block, block, h, w).reshape(n, cp, h, w)[:, :c]
 
 
+H4_SKIP_FIRST = 0   # Mconv1 experiments: no correction for the first n input channels (the re-injected 57 head maps)
+
+
 def conv_h4(x, w, b, pad, comp_a=True, comp_w=True, block=32, lo_shift=11):
+    if H4_SKIP_FIRST and x.shape[1] > 128:
+        n = x.shape[1] - 128
+        y0 = F.conv2d(x[:, :n].half().float(), w[:, :n].half().float(), None, padding=pad)
+        return y0 + conv_h4(x[:, n:], w[:, n:], b, pad, comp_a, comp_w, block, lo_shift)
     """hi*hi in fp16 + fp4 (e2m1, MX block scales) error compensation: a_lo4 * W4 + a4 * W_lo4.
     activations: one E8M0 scale per (pixel, 32 channels) from the block maximum; weights: one static scale per layer"""
     xh = x.half().float(); wh = w.half().float()
@@ -103,14 +110,15 @@ def conv_h4(x, w, b, pad, comp_a=True, comp_w=True, block=32, lo_shift=11):
     sw = float(np.ceil(np.log2(float(w.abs().max()) / MINIFLOAT[fw][3])))
     if comp_a:
         xlo = x - xh
-        sl = s - lo_shift
+        sl = blk_exp(xlo, block) if lo_shift < 0 else s - lo_shift   # lo_shift < 0: the lo block gets its own scale from max |lo|
         a4 = fp4_round(xlo / 2.0 ** sl) * 2.0 ** sl
         w4 = fp4_round(wh / 2.0 ** sw, fw) * 2.0 ** sw
         y = y + F.conv2d(a4, w4, None, padding=pad)
     if comp_w:
         wlo = w - wh
         a4 = fp4_round(xh / 2.0 ** s) * 2.0 ** s
-        w4 = fp4_round(wlo / 2.0 ** (sw - lo_shift), fw) * 2.0 ** (sw - lo_shift)
+        swl = float(np.ceil(np.log2(max(float(wlo.abs().max()), 1e-30) / MINIFLOAT[fw][3]))) if lo_shift < 0 else sw - lo_shift
+        w4 = fp4_round(wlo / 2.0 ** swl, fw) * 2.0 ** swl
         y = y + F.conv2d(a4, w4, None, padding=pad)
     return y
 
@@ -185,18 +193,19 @@ H4_LO = 11
 
 
 def main():
-    global H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W
+    global H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W, H4_SKIP_FIRST
     ap = argparse.ArgumentParser()
     ap.add_argument("--h4_block", type=int, default=32)
     ap.add_argument("--h4_lo", type=int, default=11)
     ap.add_argument("--h4_fmt", default="e2m1", choices=sorted(MINIFLOAT))
     ap.add_argument("--h4_fmt_w", default=None, choices=sorted(MINIFLOAT))
+    ap.add_argument("--h4_skip_heads", type=int, default=0)
     ap.add_argument("--w", type=int, default=160)
     ap.add_argument("--h", type=int, default=96)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("modes", nargs="+")
     a = ap.parse_args()
-    H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W = a.h4_block, a.h4_lo, a.h4_fmt, a.h4_fmt_w
+    H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W, H4_SKIP_FIRST = a.h4_block, a.h4_lo, a.h4_fmt, a.h4_fmt_w, a.h4_skip_heads
     torch.set_num_threads(os.cpu_count())
     rs = np.random.RandomState(a.seed)
     x = torch.from_numpy((rs.randint(0, 256, size=(1, 3, a.h, a.w)).astype(np.float32) / 256.0 - 0.5))
