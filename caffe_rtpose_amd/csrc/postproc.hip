@@ -629,8 +629,12 @@ __device__ __forceinline__ void limb_setup(const ConnectParams& p, int k, const 
   if (nB > p.max_peaks) nB = p.max_peaks;
 }
 
+// Workgroups of 1024 threads = four 256-pair blocks of one limb: the limb's two PAF planes are staged into LDS once for all four, and
+// the 304 small workgroups that used to land one or two per CU (each blocking a whole CU for a convolution workgroup of another
+// frame) become 76 dense ones.  Survivors are still compacted per block of 256 pairs (cand_blk), so the results are unchanged.
+#define PAIRS_WG 1024
 template <bool FUSED>
-__global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, ResizeParams r, int stage) {
+__global__ __launch_bounds__(PAIRS_WG) void connect_pairs_kernel(ConnectParams p, ResizeParams r, int stage) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int k = blockIdx.y;
   const int cap = p.max_peaks * p.max_peaks;
@@ -642,11 +646,14 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, Res
   const float *candA, *candB;
   int nA, nB;
   limb_setup(p, k, candA, candB, nA, nB);
-  __shared__ int wave_cnt[4];
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  __shared__ int wave_cnt[PAIRS_WG / 64];
+  const int q = blockIdx.x * PAIRS_WG + threadIdx.x;
+  const int sub = threadIdx.x >> 8;                      // 256-pair block of this thread inside the workgroup
+  const int blk256 = blockIdx.x * (PAIRS_WG / 256) + sub;  // ... and inside the limb (the unit of cand_blk)
+  const int nblk256 = (p.max_peaks * p.max_peaks + 255) / 256;
   const int npairs = nA * nB;
-  if (blockIdx.x * 256 >= npairs) {  // whole block past the last pair (uniform)
-    if (threadIdx.x == 0) p.cand_blk[k * gridDim.x + blockIdx.x] = 0;
+  if (blockIdx.x * PAIRS_WG >= npairs) {  // whole workgroup past the last pair (uniform)
+    if ((threadIdx.x & 255) == 0 && blk256 < nblk256) p.cand_blk[k * nblk256 + blk256] = 0;
     return;
   }
   // FUSED: the limb's two PAF channels (all scales) go to LDS once per workgroup; the 20 bicubic
@@ -660,7 +667,7 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, Res
       for (int n = 0; n < r.num; ++n) {
         const float* src = r.src + ((long)n * r.C + mapIdx[2 * k + which]) * lplane;
         float* dst = lmap + ((long)which * r.num + n) * lplane;
-        for (int o = threadIdx.x; o < (int)lplane; o += 256) dst[o] = src[o];
+        for (int o = threadIdx.x; o < (int)lplane; o += PAIRS_WG) dst[o] = src[o];
       }
     __syncthreads();
   }
@@ -721,19 +728,20 @@ __global__ __launch_bounds__(256) void connect_pairs_kernel(ConnectParams p, Res
     }
   }
   }
-  // survivors of this block, compacted in loop order at the head of the block's 256 slots
+  // survivors of every 256-pair block, compacted in loop order at the head of the block's 256 slots
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long bal = __ballot(pass);
   if (lane == 0) wave_cnt[wave] = __popcll(bal);
   __syncthreads();
   int before = 0;
-  for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+  for (int w = sub * 4; w < wave; ++w) before += wave_cnt[w];
   const int lo = before + __popcll(bal & ((1ull << lane) - 1ull));
   if (pass) {
-    p.cand_score[(long)k * cap + blockIdx.x * 256 + lo] = conn_score;
-    p.cand_ij[(long)k * cap + blockIdx.x * 256 + lo] = (i << 16) | j;
+    p.cand_score[(long)k * cap + blk256 * 256 + lo] = conn_score;
+    p.cand_ij[(long)k * cap + blk256 * 256 + lo] = (i << 16) | j;
   }
-  if (threadIdx.x == 0) p.cand_blk[k * gridDim.x + blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  if ((threadIdx.x & 255) == 0 && blk256 < nblk256)
+    p.cand_blk[k * nblk256 + blk256] = wave_cnt[sub * 4] + wave_cnt[sub * 4 + 1] + wave_cnt[sub * 4 + 2] + wave_cnt[sub * 4 + 3];
 }
 
 // 64-bit sort key: ascending key order == (score descending, loop order ascending)
@@ -1113,8 +1121,8 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
       e = ensure_lds<connect_pairs_kernel<true>>(lds0);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), stage ? lds0 : 0, stream, p, *r, stage);
-  } else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + 255) / 256, p.num_limbs), dim3(256), 0, stream, p, ResizeParams{}, 0);
+    hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + PAIRS_WG - 1) / PAIRS_WG, p.num_limbs), dim3(PAIRS_WG), stage ? lds0 : 0, stream, p, *r, stage);
+  } else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + PAIRS_WG - 1) / PAIRS_WG, p.num_limbs), dim3(PAIRS_WG), 0, stream, p, ResizeParams{}, 0);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(connect_match_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
