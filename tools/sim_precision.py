@@ -27,7 +27,11 @@ import ctypes as C  # noqa: E402
 from caffe_rtpose_amd._lib import lib  # noqa: E402
 
 
-def synth(name, cout, cin, k, seed=1):
+WSEED = 1
+
+
+def synth(name, cout, cin, k, seed=None):
+    seed = WSEED if seed is None else seed
     w = np.empty((cout, cin, k, k), np.float32)
     b = np.empty((cout,), np.float32)
     fp = C.POINTER(C.c_float)
@@ -193,19 +197,21 @@ H4_LO = 11
 
 
 def main():
-    global H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W, H4_SKIP_FIRST
+    global H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W, H4_SKIP_FIRST, WSEED
     ap = argparse.ArgumentParser()
     ap.add_argument("--h4_block", type=int, default=32)
     ap.add_argument("--h4_lo", type=int, default=11)
     ap.add_argument("--h4_fmt", default="e2m1", choices=sorted(MINIFLOAT))
     ap.add_argument("--h4_fmt_w", default=None, choices=sorted(MINIFLOAT))
     ap.add_argument("--h4_skip_heads", type=int, default=0)
+    ap.add_argument("--wseed", type=int, default=1, help="seed of the synthetic weights (the engine's rtp_config.synthetic_seed)")
     ap.add_argument("--w", type=int, default=160)
     ap.add_argument("--h", type=int, default=96)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("modes", nargs="+")
     a = ap.parse_args()
     H4_BLOCK, H4_LO, H4_FMT, H4_FMT_W, H4_SKIP_FIRST = a.h4_block, a.h4_lo, a.h4_fmt, a.h4_fmt_w, a.h4_skip_heads
+    WSEED = a.wseed
     torch.set_num_threads(os.cpu_count())
     rs = np.random.RandomState(a.seed)
     x = torch.from_numpy((rs.randint(0, 256, size=(1, 3, a.h, a.w)).astype(np.float32) / 256.0 - 0.5))
