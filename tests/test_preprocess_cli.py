@@ -229,6 +229,21 @@ def test_cli_write_frames_jpeg_equals_library_render(tmp_path):
     e.close()
     p = subprocess.run([BIN, "--video", "synthetic:64x48:1", "--model", "coco", "--write_frames", str(tmp_path / "x"), "--host_preprocess"], capture_output=True)
     assert p.returncode == 1 and b"--write_frames needs" in p.stderr
+    # --part_to_show N: the files hold the heat-map / PAF view render() draws (rtpose.cpp:270-299) = rtp_config.render = 1 + N in the library
+    out2 = tmp_path / "views"
+    p = subprocess.run([BIN, "--video", "synthetic:640x480:2:5", "--model", "coco", "--net_resolution", "160x96", "--resolution", "320x240",
+                        "--write_frames", str(out2), "--part_to_show", "19", "--no_frame_drops", "--no_display", "--num_gpu", "1"], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    e = r.Engine(r.Config(net_w=160, net_h=96, disp_w=320, disp_h=240, frames_in_flight=1, render=1 + 19))
+    for i in range(2):
+        e.submit_frame(r.synth_frame(640, 480, i, seed=5), tag=i)
+        _, n, joints, img = e.collect_rendered()
+        data = open(out2 / f"frame{i:06d}.jpg", "rb").read()
+        assert data == r.encode_jpeg(img, 98)
+        assert data != open(out / f"frame{i:06d}.jpg", "rb").read()
+    e.close()
+    p = subprocess.run([BIN, "--video", "synthetic:64x48:1", "--model", "coco", "--write_frames", str(tmp_path / "y"), "--part_to_show", "40", "--no_display"], capture_output=True)
+    assert p.returncode != 0   # outside the COCO model's maps
 
 
 def test_cli_reorderer_order_drops_and_window(tmp_path):
