@@ -25,9 +25,6 @@
 #include <type_traits>
 
 #include "conv_common.h"
-#ifndef ILV_EXP
-#define ILV_EXP 0
-#endif
 
 namespace rtp {
 
@@ -46,9 +43,6 @@ template <int CHB, int TM, bool ILV> __device__ __forceinline__ int ring_swz_a(i
 // every lane takes the value of the next higher lane (v_mov_b32_dpp wave_shl:1).  bound_ctrl: lane 63 (no source) gets 0 and
 // the destination is not tied to an "old" value (with old = src hipcc emitted a v_mov in front of every DPP move)
 __device__ __forceinline__ uint4 lanes_down1(const uint4& v) {
-#if ILV_EXP == 2
-  return v;
-#endif
   uint4 r;
   r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130, 0xf, 0xf, true);
   r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x130, 0xf, 0xf, true);
@@ -449,11 +443,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     // ILV: the one row the shift cannot supply (lanes 31 and 63 of fragment TM-1): exec-masked reads, see lds_read_lanes
     auto read_boundary_c = [&](auto s_tag, int abuf_) __attribute__((always_inline)) {
       constexpr int s = decltype(s_tag)::value;
-#if ILV_EXP != 1
 #pragma unroll
       for (int gi = 0; gi < GPW; ++gi)
         lds_read_lanes(na_[gi][TM - 1], lds_addr_of((const unsigned char*)a_ilv(TM - 1, s, abuf_, 2 * (kg * GPW + gi) + lhalf)), 0x8000000080000000ull);
-#endif
     };
     // MFMA #m of the tap being multiplied.  MQ: fp8 compensation tap — k-block jj of this wave is the (kg*NKB + jj)-th of the
     // chunk: even = a_lo8 x W8, odd = a8 x W_lo8.
