@@ -234,7 +234,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   const BlockCoord bc = decode_block(P, P.CoutP / BN, P.tiles_per_img * P.nimg);
   const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;
-  if (P.tstamp && tid == 0) atomicMax(&P.tstamp[0], ~(unsigned long long)wall_clock64());  // slot = {~(min start), max end}, both zero-initialised
   unsigned long long clk0 = 0, wall0 = 0;
   if (P.clkprobe && tid == 0 && blockIdx.x == 0) { clk0 = clock64(); wall0 = wall_clock64(); }
   const int lane = tid & 63;
@@ -553,10 +552,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     wait_vmcnt<63>();
     __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
     conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
-    if (P.tstamp && tid == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      atomicMax(&P.tstamp[1], (unsigned long long)wall_clock64());
-    }
     if (P.clkprobe && tid == 0 && blockIdx.x == 0) {  // shader-clock cycles vs 100 MHz wall clock over this workgroup's life
       P.clkprobe[0] = clock64() - clk0;
       P.clkprobe[1] = wall_clock64() - wall0;
@@ -648,10 +643,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   __builtin_amdgcn_s_barrier();
 
   conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
-  if (P.tstamp && tid == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
-    atomicMax(&P.tstamp[1], (unsigned long long)wall_clock64());
-  }
 }
 
 #ifndef RTP_RING_NO_LAUNCHERS  // (tools/ring_probe.hip instantiates single kernels to inspect their ISA)

@@ -136,17 +136,11 @@ struct Ctx {
   bool launched = false;
   // RTP_EXEC_GRAPH: the whole batch (conv stack, every frame's post-processing chain, D2H) captured once
   // per (timed?, frames in the batch) and replayed; gev = {before, after} the replay on `stream`
-  hipGraphExec_t gexec[2][17] = {};
+  hipGraphExec_t gexec[17] = {};
   hipEvent_t gev[2] = {nullptr, nullptr};
   bool graph_run = false;                 // the batch in flight was ONE graph replay incl. post-processing (collect waits on gev[1])
   bool graph_conv = false;                // the conv stack was a replay, the post-processing chains were launched eagerly
-  unsigned long long* ts_dev = nullptr;   // in-kernel {~start, end} stamps of the dominant-class launches of one replay
-  unsigned long long* ts_host = nullptr;  // pinned copy, written by the graph after the conv stack
-  int ts_n = 0;
-  unsigned char ts_pass[64] = {};         // MFMA passes (1..3) of the launch behind slot i
-  bool ts_pending = false;
 };
-const int CTX_TS_SLOTS = 64;
 
 }  // namespace
 
@@ -188,7 +182,12 @@ struct rtp_engine {
   long dom_launches = 0;
   double dom_ms_pass[4] = {0, 0, 0, 0};   // the same, by MFMA passes of the launch (split-precision layers run 2-3)
   long dom_n_pass[4] = {0, 0, 0, 0};
-  std::vector<unsigned char> ts_ring_pass;
+  // rtp_kernel_timing: one HIP event pair around every dominant-class launch (recorded on the launch's own stream; batches are
+  // launched eagerly while it is on).  Nothing here compares clocks of different XCDs.
+  std::vector<hipEvent_t> tev;            // 2 * pairs
+  std::vector<unsigned char> tev_pass;    // MFMA passes (1..3) of the launch behind pair i
+  int tev_next = 0;
+  static const int TEV_PAIRS = 4096;
   // device-side pre-processing (row a1)
   const short* warp_tab_dev = nullptr;  // inside prep_tables
   std::vector<AreaScale> area_scales;   // device pointers inside prep_tables
@@ -199,9 +198,6 @@ struct rtp_engine {
   bool graph_post = false;  // RTP_GRAPH_POST=1: also capture the per-frame post-processing chains + D2H into the batch graph
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
   std::string split_rules;
-  unsigned long long* ts_ring = nullptr;  // device: {~(min start), max end} per timed launch (eager mode)
-  int ts_next = 0;
-  static const int TS_SLOTS = 32768;
 };
 
 namespace {
@@ -558,12 +554,12 @@ int build_plan(rtp_engine* e) {
     const int ksplit = c.cfg == CFG_128x128 ? 1 : (c.cfg == CFG_64x64 ? (c.rowb == 128 ? 2 : 4) : 2);
     const int gpw = (c.rowb / 32) / ksplit;
     c.h8 = e->split_fp8 && e->mode == RTP_PREC_MIXED && e->prec == 0 && c.impl == 1 && c.split_a && c.split_w && gpw >= 2 && gpw % 2 == 0;
-    if (c.split_a) { if (c.h8) e->tensors[c.in_tensor].need_q = true; else e->tensors[c.in_tensor].need_lo = true; }
   }
   for (auto& s : e->steps)  // both branches of a pair run the same kernel
-    if (s.type == 1 && s.b >= 0 && e->convs[s.a].h8 != e->convs[s.b].h8) {
-      for (int idx : {s.a, s.b}) { ConvOp& c = e->convs[idx]; if (c.h8) { c.h8 = false; e->tensors[c.in_tensor].need_lo = true; } }
-    }
+    if (s.type == 1 && s.b >= 0 && e->convs[s.a].h8 != e->convs[s.b].h8)
+      for (int idx : {s.a, s.b}) e->convs[idx].h8 = false;
+  for (auto& c : e->convs)  // which operand blocks the input tensors must carry, from the FINAL flags
+    if (c.split_a) { if (c.h8) e->tensors[c.in_tensor].need_q = true; else e->tensors[c.in_tensor].need_lo = true; }
   for (size_t pi = e->pools.size(); pi-- > 0;) {  // a pool output with lo / q parts needs them in its input
     if (e->tensors[e->pools[pi].out_tensor].need_lo) e->tensors[e->pools[pi].in_tensor].need_lo = true;
     if (e->tensors[e->pools[pi].out_tensor].need_q) e->tensors[e->pools[pi].in_tensor].need_q = true;
@@ -598,7 +594,7 @@ int build_plan(rtp_engine* e) {
       auto chain = [&](int ia, int ic) {
         const ConvOp& A = e->convs[ia];
         const ConvOp& C = e->convs[ic];
-        return A.k == 1 && C.k == 1 && !A.first && A.Cin_p == 128 && A.cout % 128 == 0 && C.cin == A.cout && A.dsts.size() == 1 &&
+        return A.k == 1 && C.k == 1 && !A.first && A.Cin_p == 128 && A.cout % 128 == 0 && A.cout <= 512 /* conv_pw2.hip PW_MAXMID */ && C.cin == A.cout && A.dsts.size() == 1 &&
                C.in_tensor == A.dsts[0].first && C.cout <= 64 && e->tensors[A.dsts[0].first].C == A.cout;
       };
       if (!chain(s1.a, s2.a) || (s1.b >= 0 && !chain(s1.b, s2.b))) continue;
@@ -645,6 +641,10 @@ int build_plan(rtp_engine* e) {
   }
   e->strip_rows = e->N > 1 ? 16 : 8;  // several scales: the row interpolations of a strip are the larger share, taller strips amortise them (+3 % frames/s at 3 scales)
   if (const char* sr = getenv("RTP_NMS_STRIP_ROWS")) { const int v = atoi(sr); if (v >= 2 && v <= 16) e->strip_rows = v; }  // experiments
+  // the strip kernel keeps (strip_rows + 2 + NMSF_TROWS) rows of W floats + a W x 8-byte column table in LDS (postproc.hip, 150 KiB cap)
+  while (e->strip_rows > 2 && ((size_t)(e->strip_rows + 2 + 8 /* NMSF_TROWS */) * e->cfg.net_w * 4 + (size_t)e->cfg.net_w * 8) > 150 * 1024) e->strip_rows /= 2;
+  if (((size_t)(e->strip_rows + 2 + 8 /* NMSF_TROWS */) * e->cfg.net_w * 4 + (size_t)e->cfg.net_w * 8) > 150 * 1024)
+    return fail(e, RTP_EINVAL, "net_resolution width %d is too large for the fused ImResize+Nms strip kernel", e->cfg.net_w);
   e->nstrips = (e->cfg.net_h + e->strip_rows - 1) / e->strip_rows;
   e->max_rows = e->num_limbs * e->max_peaks;
   {
@@ -826,7 +826,7 @@ void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProbl
 }
 
 unsigned long long* g_clkprobe = nullptr;  // diagnostics (rtp_bench_dominant_conv under RTP_CLKPROBE)
-int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned long long* tstamp = nullptr) {
+int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   const ConvOp& A = e->convs[s.a];
   const Geom& g = e->geom[A.level];
   ConvParams P;
@@ -850,7 +850,6 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg, unsigned l
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
   P.relu = A.relu ? 1 : 0;
-  P.tstamp = tstamp;
   P.clkprobe = g_clkprobe;
   P.nimg = nimg;
   {
@@ -963,20 +962,20 @@ int launch_first_step(rtp_engine* e, Ctx& cx, const Step& s, const float* input_
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bool cap = false) {
   const std::vector<PoolOp>& pools = e->pools;
   auto geom_n = [&](int level) { Geom g = e->geom[level]; g.N = nimg; return g; };
-  if (cap) cx.ts_n = 0;
   for (auto& s : e->steps) {
     if (s.type == 0) {
       const Tensor& t = e->tensors[0];
       HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, geom_n(0), t.stride(), cx.stream));
     } else if (s.type == 1) {
-      unsigned long long* ts = nullptr;
-      if (e->time_dominant && is_dominant_class(e, s)) {
-        const unsigned char np = (unsigned char)e->convs[s.a].passes();
-        if (cap) { if (cx.ts_dev && cx.ts_n < CTX_TS_SLOTS) { cx.ts_pass[cx.ts_n] = np; ts = cx.ts_dev + 2 * (size_t)cx.ts_n++; } }
-        else if (e->ts_ring && e->ts_next < rtp_engine::TS_SLOTS) { e->ts_ring_pass[e->ts_next] = np; ts = e->ts_ring + 2 * (size_t)e->ts_next++; }
-      }
-      const int rc = launch_conv_step(e, cx, s, nimg, ts);
+      // timing pass: an event pair on this stream around the launch (full batches only: the FLOP count reported is the full batch's)
+      const bool timed = e->time_dominant && !cap && nimg == e->NI && is_dominant_class(e, s) && e->tev_next < (int)e->tev.size() / 2;
+      if (timed) HIPCHK(e, hipEventRecord(e->tev[2 * (size_t)e->tev_next], cx.stream));
+      const int rc = launch_conv_step(e, cx, s, nimg);
       if (rc) return rc;
+      if (timed) {
+        HIPCHK(e, hipEventRecord(e->tev[2 * (size_t)e->tev_next + 1], cx.stream));
+        e->tev_pass[e->tev_next++] = (unsigned char)e->convs[s.a].passes();
+      }
     } else if (s.type == 3) {
       const int rc = launch_pw2_step(e, cx, s, nimg);
       if (rc) return rc;
@@ -1054,10 +1053,6 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
   if (part & 1) {
     HIPCHK(e, hipEventRecord(cx.ev[0], cx.stream));
     if ((rc = run_frame_stack(e, cx, input_dev, nframes * e->N, cap))) return rc;
-    if (cap && cx.ts_n > 0) {  // hand the stamps of this replay to the host and re-arm the slots
-      HIPCHK(e, hipMemcpyAsync(cx.ts_host, cx.ts_dev, (size_t)2 * cx.ts_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, cx.stream));
-      HIPCHK(e, hipMemsetAsync(cx.ts_dev, 0, (size_t)2 * cx.ts_n * sizeof(unsigned long long), cx.stream));
-    }
   }
   if (!(part & 2)) return RTP_OK;
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
@@ -1131,7 +1126,8 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
   int rc;
   static const char* diag = getenv("RTP_DIAG_SKIP_POST");
   static const char* unf = getenv("RTP_POST_UNFUSED");
-  const bool graph = e->use_graph && !materialize && input_dev == cx.input && !e->cfg.render && !diag && !unf && nframes <= 16;
+  // (a timing pass launches eagerly: its event pairs sit between the launches)
+  const bool graph = e->use_graph && !e->time_dominant && !materialize && input_dev == cx.input && !e->cfg.render && !diag && !unf && nframes <= 16;
   cx.graph_run = graph;
   cx.graph_conv = false;
   if (!graph) {
@@ -1139,22 +1135,15 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
     cx.launched = true;
     return RTP_OK;
   }
-  const int t = e->time_dominant ? 1 : 0;
-  if (t && !cx.ts_dev) {
-    HIPCHK(e, hipMalloc((void**)&cx.ts_dev, (size_t)2 * CTX_TS_SLOTS * sizeof(unsigned long long)));
-    HIPCHK(e, hipMemset(cx.ts_dev, 0, (size_t)2 * CTX_TS_SLOTS * sizeof(unsigned long long)));
-    HIPCHK(e, hipHostMalloc((void**)&cx.ts_host, (size_t)2 * CTX_TS_SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
-  }
-  if (!cx.gexec[t][nframes] && (rc = capture_batch(e, cx, nframes, &cx.gexec[t][nframes]))) return rc;
+  if (!cx.gexec[nframes] && (rc = capture_batch(e, cx, nframes, &cx.gexec[nframes]))) return rc;
   HIPCHK(e, hipEventRecord(cx.gev[0], cx.stream));
-  HIPCHK(e, hipGraphLaunch(cx.gexec[t][nframes], cx.stream));
+  HIPCHK(e, hipGraphLaunch(cx.gexec[nframes], cx.stream));
   if (!e->graph_post) {  // the conv stack is one replay; every frame's short post-processing chain is launched eagerly on its slot's stream
     if ((rc = launch_batch_body(e, cx, nframes, cx.input, false, false, 2))) return rc;
     cx.graph_run = false;            // collect waits for the frame's own event, not for the whole batch
     cx.graph_conv = true;
   }
   HIPCHK(e, hipEventRecord(cx.gev[1], cx.stream));
-  cx.ts_pending = t != 0;
   cx.launched = true;
   return RTP_OK;
 }
@@ -1245,11 +1234,10 @@ void free_ctx(Ctx& cx) {
     for (int i = 0; i < 5; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
   }
-  for (auto& row : cx.gexec) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-  void* dptrs[] = {cx.arena, cx.input, cx.lowres, cx.ts_dev};
+  for (hipGraphExec_t& g : cx.gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+  void* dptrs[] = {cx.arena, cx.input, cx.lowres};
   for (void* p : dptrs) if (p) (void)hipFree(p);
   if (cx.host_in) (void)hipHostFree(cx.host_in);
-  if (cx.ts_host) (void)hipHostFree(cx.ts_host);
   for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
   for (int i = 0; i < 2; ++i) if (cx.gev[i]) (void)hipEventDestroy(cx.gev[i]);
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
@@ -1258,6 +1246,17 @@ void free_ctx(Ctx& cx) {
 
 int use_device(rtp_engine* e) {
   HIPCHK(e, hipSetDevice(e->cfg.device_id));
+  return RTP_OK;
+}
+
+// A captured batch graph bakes every by-value kernel argument (ConvParams::wq_exp of the fp8-compensated layers; with
+// RTP_GRAPH_POST=1 also the thresholds and scales of the post-processing chains).  Whoever changes one of those drops the
+// graphs; launch_batch re-captures on the next batch.  Needs an idle engine.
+int invalidate_graphs(rtp_engine* e) {
+  for (Ctx& cx : e->ctx) {
+    if (cx.stream) HIPCHK(e, hipStreamSynchronize(cx.stream));
+    for (hipGraphExec_t& g : cx.gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+  }
   return RTP_OK;
 }
 
@@ -1404,7 +1403,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   for (auto& c : e->ctx) free_ctx(c);
   if (e->dweights) (void)hipFree(e->dweights);
   if (e->dchmap) (void)hipFree(e->dchmap);
-  if (e->ts_ring) (void)hipFree(e->ts_ring);
+  for (hipEvent_t ev : e->tev) if (ev) (void)hipEventDestroy(ev);
   if (e->prep_tables) (void)hipFree(e->prep_tables);
   delete e;
 }
@@ -1539,7 +1538,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   }
   if (e->use_graph && !e->cfg.render)  // capture the full-batch plan of every context now, not inside the first frames
     for (auto& c : e->ctx)
-      if ((rc = capture_batch(e, c, e->B, &c.gexec[0][e->B]))) return bail(rc);
+      if ((rc = capture_batch(e, c, e->B, &c.gexec[e->B]))) return bail(rc);
   *out = e;
   return RTP_OK;
 }
@@ -1554,9 +1553,15 @@ int rtp_engine_info(const rtp_engine* e, int* num_parts, int* max_peaks, int* he
   return RTP_OK;
 }
 
+static int need_idle(rtp_engine* e);
 int rtp_set_thresholds(rtp_engine* e, float nms_threshold, float connect_inter_threshold, int connect_inter_min_above_threshold,
                        int connect_min_subset_cnt, float connect_min_subset_score) {
   if (!e) return RTP_EINVAL;
+  if (e->graph_post && !e->ctx.empty()) {  // the post-processing chains live inside the batch graphs: their arguments are baked
+    int rc;
+    if ((rc = need_idle(e))) return rc;
+    if ((rc = invalidate_graphs(e))) return rc;
+  }
   e->nms_threshold = nms_threshold;
   e->inter_threshold = connect_inter_threshold;
   e->inter_min_above = connect_inter_min_above_threshold;
@@ -1582,6 +1587,7 @@ int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap) {
     if ((rc = use_device(e))) return rc;
     HIPCHK(e, hipDeviceSynchronize());
     if ((rc = build_prep_tables(e))) return rc;
+    if (e->graph_post && (rc = invalidate_graphs(e))) return rc;
   }
   return RTP_OK;
 }
@@ -1703,19 +1709,6 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   Slot& sl = cx.slot[sj];
   if (!cx.launched && (rc = launch_open(e))) return rc;  // the oldest frame sits in a partial batch
   HIPCHK(e, hipEventSynchronize(cx.graph_run ? cx.gev[1] : sl.ev[4]));
-  if ((cx.graph_run || cx.graph_conv) && cx.ts_pending) {  // dominant-kernel stamps of this replay (rtp_kernel_timing)
-    int khz = 100000;
-    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
-    for (int i = 0; i < cx.ts_n; ++i) {
-      const unsigned long long st = ~cx.ts_host[2 * i], en = cx.ts_host[2 * i + 1];
-      if (cx.ts_host[2 * i] != 0 && en > st) {
-        const double ms = (double)(en - st) / (double)khz;
-        e->dom_ms_total += ms; e->dom_launches++;
-        e->dom_ms_pass[cx.ts_pass[i] & 3] += ms; e->dom_n_pass[cx.ts_pass[i] & 3]++;
-      }
-    }
-    cx.ts_pending = false;
-  }
   e->fifo.pop_front();
   sl.busy = false;
   bool any = false;
@@ -1966,8 +1959,12 @@ int rtp_set_conv_weights(rtp_engine* e, int i, const float* w, const float* b) {
     std::vector<int> old(e->convs.size());
     for (size_t j = 0; j < e->convs.size(); ++j) old[j] = e->convs[j].wq_exp;
     compute_wq_exp(e);
-    for (size_t j = 0; j < e->convs.size(); ++j)
+    bool moved = false;
+    for (size_t j = 0; j < e->convs.size(); ++j) {
+      moved = moved || e->convs[j].wq_exp != old[j];
       if ((int)j != i && e->convs[j].wq_exp != old[j] && (rc = upload_conv_weights(e, (int)j))) return rc;
+    }
+    if (moved && (rc = invalidate_graphs(e))) return rc;  // ConvParams::wq_exp is a by-value argument baked into the captured graphs
   }
   return upload_conv_weights(e, i);
 }
@@ -2202,22 +2199,17 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
   if (!e) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
-  // harvest the timestamp ring: every used slot holds {first workgroup start, last workgroup end}
-  if (e->ts_ring && e->ts_next > 0 && e->fifo.empty()) {
+  // harvest the event pairs: each brackets ONE dominant-class launch on the stream it ran on
+  if (e->tev_next > 0 && e->fifo.empty()) {
     HIPCHK(e, hipDeviceSynchronize());
-    std::vector<unsigned long long> h((size_t)2 * e->ts_next);
-    HIPCHK(e, hipMemcpy(h.data(), e->ts_ring, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    int khz = 100000;
-    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
-    for (int i = 0; i < e->ts_next; ++i) {
-      const unsigned long long st = ~h[2 * i], en = h[2 * i + 1];
-      if (h[2 * i] != 0 && en > st) {
-        const double ms = (double)(en - st) / (double)khz;
+    for (int i = 0; i < e->tev_next; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e->tev[2 * (size_t)i], e->tev[2 * (size_t)i + 1]) == hipSuccess && ms > 0.f) {
         e->dom_ms_total += ms; e->dom_launches++;
-        e->dom_ms_pass[e->ts_ring_pass[i] & 3] += ms; e->dom_n_pass[e->ts_ring_pass[i] & 3]++;
+        e->dom_ms_pass[e->tev_pass[i] & 3] += ms; e->dom_n_pass[e->tev_pass[i] & 3]++;
       }
     }
-    e->ts_next = 0;
+    e->tev_next = 0;
   }
   if (total_ms) *total_ms = e->dom_ms_total;
   if (launches) *launches = e->dom_launches;
@@ -2238,10 +2230,12 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     }
     e->time_dominant = enable != 0;
     if (e->time_dominant) {
-      if (!e->ts_ring) HIPCHK(e, hipMalloc((void**)&e->ts_ring, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
-      e->ts_ring_pass.assign(rtp_engine::TS_SLOTS, 1);
-      HIPCHK(e, hipMemset(e->ts_ring, 0, (size_t)2 * rtp_engine::TS_SLOTS * sizeof(unsigned long long)));
-      e->ts_next = 0;
+      if (e->tev.empty()) {
+        e->tev.assign((size_t)2 * rtp_engine::TEV_PAIRS, nullptr);
+        for (hipEvent_t& ev : e->tev) HIPCHK(e, hipEventCreate(&ev));
+        e->tev_pass.assign(rtp_engine::TEV_PAIRS, 1);
+      }
+      e->tev_next = 0;
     }
   }
   return RTP_OK;

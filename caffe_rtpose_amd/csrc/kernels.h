@@ -66,10 +66,6 @@ struct ConvParams {
   int spec;    // ring kernel: 1 = wave-specialised variant (4 DMA waves + 4 MFMA waves)
   int variant; // ring kernel experiments (env RTP_RING_VAR; see conv_ring.hip), 0 = production
   int ilv;     // ring kernel (wave-specialised, fp16): interleaved A-fragment rows, taps 1.. of a strip shift registers instead of re-reading LDS
-  // optional {min start, max end} wall_clock64() slot of this launch (bench.py's in-situ kernel
-  // timing: what a profiler's kernel trace reports, unlike stream events which also count the time
-  // a launch queues behind other frames' kernels)
-  unsigned long long* tstamp;
   unsigned long long* clkprobe;  // diagnostics: {shader clock cycles, wall clock ticks} of workgroup 0 (spec ring kernels)
 };
 

@@ -12,7 +12,7 @@
 // element against the real std::sort (g++ 11) on tie-heavy inputs.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RTP_HD __host__ __device__
 #else
 #define RTP_HD

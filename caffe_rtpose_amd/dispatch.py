@@ -15,9 +15,9 @@ def frame_shard(total_frames, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def timed_region(run_fn, steps, warmup, dist=None, device_sync=None, reduce_device=None):
+def timed_region(run_fn, steps, warmup, dist=None, device_sync=None, reduce_device=None, return_local=False):
     """warmup untimed steps, then `steps` steps bracketed by barrier + device sync on both sides.
-    Returns the MAX over ranks of the elapsed seconds (what the whole job waited for)."""
+    Returns the MAX over ranks of the elapsed seconds (what the whole job waited for); with return_local also this rank's own."""
     def fence():
         if device_sync:
             device_sync()
@@ -33,12 +33,13 @@ def timed_region(run_fn, steps, warmup, dist=None, device_sync=None, reduce_devi
     run_fn(steps, 1 << 20)
     fence()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=reduce_device or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt
+    return (dt, dt_local) if return_local else dt
 
 
 def scaled_steps(steps, est_steps_per_s, min_seconds, dist=None):

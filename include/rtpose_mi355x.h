@@ -267,10 +267,12 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms_per_step, double* gflo
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch);
 /* In-situ timing of the dominant kernel class (every paired 7x7 128->128 launch of every frame):
  * enable = 1/0 switches it on/off (resetting the totals on a change), 2 = on AND reset, enable < 0 only
- * reads; the mode can only change on an idle engine (graph replays carry their own stamp slots).  While
- * on, each such launch records {first workgroup start, last workgroup end} of the device wall clock
- * (what a profiler's kernel trace reports; stream events would also count the time a launch queues
- * behind other frames' kernels).  Call with an idle engine to harvest. */
+ * reads; the mode can only change on an idle engine.  While on, batches are launched eagerly (no graph
+ * replay) and each such launch of a FULL batch sits between a HIP event pair recorded on the stream it
+ * runs on; the totals are the pairs' elapsed times.  Submit one batch at a time (collect it before the
+ * next) and a pair brackets its launch alone on the chip — what a profiler's kernel trace reports.
+ * Call with an idle engine to harvest.  (Round 2 compared wall-clock stamps of workgroups on different
+ * XCDs; their clocks are not synchronised on every box.) */
 int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch);
 /* The same totals split by the number of MFMA passes of the launch (1 = plain fp16 layer, 3 = split-precision layer);
  * index 0 is unused. */

@@ -23,6 +23,8 @@ CONFIGS = {  # name -> (model, W, H, num_scales, scale_gap, batch_frames)
     "coco_1s_b1": (0, 656, 368, 1, 0.3, 1),
     "coco_1s_b2": (0, 656, 368, 1, 0.3, 2),
     "coco_3s": (0, 656, 368, 3, 0.15, 1),
+    "coco_3s_b2": (0, 656, 368, 3, 0.15, 2),   # the plan bench.py's 3-scale sub-result times (6 images per launch: other tiles than 3)
+    "mpi_1s_b1": (1, 496, 368, 1, 0.3, 1),
     "mpi_1s_b2": (1, 496, 368, 1, 0.3, 2),
 }
 TOL = {"fp32": 1e-4, "f16x3": 1e-4, "mixed": 1e-3, "fp16": 3e-3}
@@ -46,8 +48,9 @@ def _reference(model, W, H, N, e):
 
 
 def _match_peaks(a, b, max_peaks):
-    """peaks [parts][max_peaks+1][3] of engine (a) and reference (b): pairs within 1 px in x and y."""
-    pairs, na, nb = [], 0, 0
+    """peaks [parts][max_peaks+1][3] of engine (a) and reference (b): pairs within 1 px in x and y, and what stayed unmatched
+    on either side as (part, x, y, score)."""
+    pairs, na, nb, lone_a, lone_b = [], 0, 0, [], []
     for p in range(a.shape[0]):
         ca = a[p, 1:1 + min(int(a[p, 0, 0]), max_peaks)]
         cb = b[p, 1:1 + min(int(b[p, 0, 0]), max_peaks)]
@@ -56,14 +59,38 @@ def _match_peaks(a, b, max_peaks):
         used = set()
         for i in range(len(ca)):
             d = np.maximum(np.abs(cb[:, 0] - ca[i, 0]), np.abs(cb[:, 1] - ca[i, 1])) if len(cb) else np.array([])
+            hit = False
             for j in np.argsort(d):
                 if d[j] > 1.0:
                     break
                 if j not in used:
                     used.add(j)
                     pairs.append((ca[i], cb[j]))
+                    hit = True
                     break
-    return pairs, na, nb
+            if not hit:
+                lone_a.append((p, *[float(v) for v in ca[i]]))
+        lone_b += [(p, *[float(v) for v in cb[j]]) for j in range(len(cb)) if j not in used]
+    return pairs, na, nb, lone_a, lone_b
+
+
+def _explain(lone, res_here, res_other, thr, norm, who):
+    """Why a peak exists on one side only: its margin to the NMS threshold and to its largest 8-neighbour on BOTH maps (a maximum
+    whose margin is below the map error flips legitimately: nms_layer.cu:15-46 compares with strict >)."""
+    for p, x, y, sc in lone:
+        xi, yi = int(round(x)), int(round(y))
+        out = []
+        for m in (res_here, res_other):
+            best = None
+            for yy in range(max(yi - 1, 1), min(yi + 2, m.shape[1] - 1)):      # the integer maximum is within 1 px of the centroid
+                for xx in range(max(xi - 1, 1), min(xi + 2, m.shape[2] - 1)):
+                    v = m[p, yy, xx]
+                    nb8 = max(m[p, yy + dy, xx + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dx or dy)
+                    if best is None or v > best[0]:
+                        best = (float(v), float(v - nb8), float(v - thr))
+            out.append(best)
+        print(f"    {who}-only peak part {p} at ({x:.2f}, {y:.2f}) score {sc / norm:.4f}: here value-max(nb8) {out[0][1] / norm:+.2e}, value-thr {out[0][2] / norm:+.2e};"
+              f" other side {out[1][1] / norm:+.2e}, {out[1][2] / norm:+.2e}")
 
 
 @pytest.mark.parametrize("mode,cfg", [(m, c) for m in ("mixed", "fp16") for c in CONFIGS] + [("f16x3", "coco_1s_b1"), ("fp32", "coco_1s_b2")])
@@ -89,12 +116,19 @@ def test_final_maps_and_keypoints_within_tolerance(mode, cfg):
     # keypoints: both sides through ImResize + Nms (bit-exact kernels), threshold on the scaled maps
     parts, max_peaks = e.num_parts, e.max_peaks
     thr = e.get_thresholds()["nms_threshold"]
-    pk_e = e.nms(e.resize(got))
-    pk_r = orc.nms(orc.imresize(ref_s, W, H, 1.0, gap)[0], parts, max_peaks, thr)
-    pairs, na, nb = _match_peaks(pk_e, pk_r, max_peaks)
-    assert nb > 50 and len(pairs) >= 0.9 * min(na, nb), f"only {len(pairs)} of {na}/{nb} peaks matched within 1 px"
+    res_e = e.resize(got)
+    res_r = orc.imresize(ref_s, W, H, 1.0, gap)[0]
+    pk_e = e.nms(res_e)
+    pk_r = orc.nms(res_r, parts, max_peaks, thr)
+    pairs, na, nb, lone_e, lone_r = _match_peaks(pk_e, pk_r, max_peaks)
     dscore = max(abs(float(a[2]) - float(b[2])) for a, b in pairs) / norm
     print(f"[{mode} {cfg}] {len(pairs)} of {na} (engine) / {nb} (reference) peaks matched within 1 px, max |d score| {dscore:.3e}")
+    _explain(lone_e, res_e, res_r, thr, norm, "engine")
+    _explain(lone_r, res_r, res_e, thr, norm, "reference")
+    # north_star: keypoints match.  The tolerance modes must reproduce >= 99 % of the peak set (what is left are maxima whose margin
+    # to a neighbour / the threshold is below the map tolerance, printed above); pure fp16 is outside the tolerance and only reported
+    need = 0.99 if mode != "fp16" else 0.95
+    assert nb > 50 and len(pairs) >= need * max(na, nb), f"only {len(pairs)} of {na}/{nb} peaks matched within 1 px"
     assert dscore <= TOL[mode]
     # the batch plan is what was checked: B frames in flight give the same maps as the frame alone
     if B > 1:
@@ -102,4 +136,79 @@ def test_final_maps_and_keypoints_within_tolerance(mode, cfg):
             e.submit(x, tag=t)
         res = [e.collect() for _ in range(B)]
         assert all(np.array_equal(res[0][2], q[2]) for q in res[1:])
+    e.close()
+
+
+def _bench_module():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rtp_bench", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("cfg", ["coco_1s_b2", "coco_3s_b2"])
+def test_people_level_parity_of_the_benched_mode(cfg):
+    """SURVEY section 7 / BASELINE.md section 3 on the configurations bench.py quotes: the engine's joints in the DEFAULT (mixed) mode
+    through rtp_submit / rtp_collect vs the full fp32 oracle chain (conv -> ImResize -> Nms -> connectLimbsCOCO), compared as sets of
+    people (a person as in rtpose.cpp:1051-1073) — the same function that writes bench.py's `parity` dict."""
+    import caffe_rtpose_amd as r
+    bench = _bench_module()
+    model, W, H, N, gap, B = CONFIGS[cfg]
+    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, scale_gap=gap, precision=r.PREC_MIXED, frames_in_flight=2 * B, batch_frames=B))
+    x, ref = _reference(model, W, H, N, e)
+    rep = bench.parity_report(e, [(x, ref, 0.0)], "coco", N, gap)
+    print(f"\n[parity {cfg}] {rep}")
+    assert rep["verdict"] != "FAIL"
+    assert rep["map_max_err"] <= 1e-3 and rep["max_dc"] <= 1e-3 and rep["max_dx_px"] <= 1.0 and rep["max_dy_px"] <= 1.0
+    assert rep["people_ref"] > 0 and rep["joints_matched"] >= 0.97 * rep["joints_ref"]
+    assert rep["people_matched"] >= 0.9 * rep["people_ref"]
+    e.close()
+
+
+def test_roofline_timing_is_plausible_and_matches_the_step_profile():
+    """bench.py's roofline comes from HIP event pairs around every dominant-class launch (rtp_kernel_timing).  It must be a
+    plausible fraction of the fp16 MFMA peak on ANY box (the round-2 driver run printed 9.5e-12 from cross-XCD clock stamps),
+    and the per-instantiation averages must agree with the same steps timed alone (rtp_profile_steps) within 25 %."""
+    import caffe_rtpose_amd as r
+    import torch
+    B = 2
+    e = r.Engine(r.Config(net_w=656, net_h=368, precision=r.PREC_MIXED, frames_in_flight=4, batch_frames=B))
+    x = torch.from_numpy(_synth.random_frame(1, 368, 656, seed=3)).cuda()
+    torch.cuda.synchronize()
+    for _ in range(3):   # warm
+        for j in range(B):
+            e.submit_device(x.data_ptr(), tag=j)
+        for j in range(B):
+            e.collect()
+    e.kernel_timing(2)
+    for b in range(10):
+        for j in range(B):
+            e.submit_device(x.data_ptr(), tag=j)
+        for j in range(B):
+            e.collect()
+    ms, n, flops = e.kernel_timing(-1)
+    byp = e.kernel_timing_by_passes()
+    e.kernel_timing(0)
+    assert n == 10 * 20 and set(byp) == {1, 2}          # 8 plain + 12 fp8-compensated paired 7x7 128->128 launches per batch
+    frac = flops / (ms / n * 1e-3) / 2.5e15
+    print(f"\n[roofline] {n} launches, {ms / n * 1e3:.1f} us each, {flops / 1e9:.2f} GFLOP -> {frac:.3f} of the fp16 peak; by passes "
+          + ", ".join(f"{p}: {t / k * 1e3:.1f} us" for p, (t, k) in byp.items()))
+    assert 0.05 < frac < 1.0
+    step_ms, step_gf = e.profile_steps(iters=20)
+    plan = [ln for ln in r.plan_summary(e.cfg).splitlines() if ln.startswith("step ")]
+    assert len(plan) == len(step_ms)
+    for passes, tag in ((1, " passes 1 "), (2, " passes 2q ")):
+        alone = [t for t, ln in zip(step_ms, plan) if " k 7 cin_p 128 cout 128 " in ln and tag in ln]
+        assert alone
+        t_alone = sum(alone) / len(alone)
+        t_ev = byp[passes][0] / byp[passes][1]
+        print(f"[roofline] passes {passes}: events {t_ev * 1e3:.1f} us, step alone {t_alone * 1e3:.1f} us")
+        assert abs(t_ev - t_alone) <= 0.25 * t_alone
+    # the graphs captured at creation still serve the next batch after the timing pass
+    for j in range(B):
+        e.submit_device(x.data_ptr(), tag=j)
+    assert [e.collect()[0] for _ in range(B)] == [0, 1]
     e.close()
