@@ -164,7 +164,7 @@ def parity_report(eng, fr, model, num_scales, scale_gap):
     import _oracle as orc
     import _parity
     mid, W, H, parts, max_peaks, thr, _ = MODELS[model]
-    reps, map_err = [], 0.0
+    reps, map_err, post_exact = [], 0.0, True
     for x, ref, _ in fr:
         norm = float(np.abs(ref).max())
         res = orc.imresize(ref, W, H, 1.0, scale_gap)[0]
@@ -174,13 +174,22 @@ def parity_report(eng, fr, model, num_scales, scale_gap):
         eng.flush()
         _, ne, je = eng.collect()
         reps.append(_parity.people_parity(je[:ne], jr[:nr], tol_px=1.0, tol_c=1e-3, c_norm=norm))
-        map_err = max(map_err, float(np.abs(eng.forward_heatmaps(x) - ref).max() / norm))
+        got = eng.forward_heatmaps(x)
+        map_err = max(map_err, float(np.abs(got - ref).max() / norm))
+        # decomposition: the reference's post-processing applied to the ENGINE's maps must give the engine's joints bit for bit;
+        # whatever differs between the two people sets is then a strict compare (Nms '>' / connect's greedy order) that the
+        # conv stack's deviation — inside the map tolerance — decides the other way
+        res_e = orc.imresize(got, W, H, 1.0, scale_gap)[0]
+        n2, j2 = orc.connect(mid, res_e, orc.nms(res_e, parts, max_peaks, thr), max_peaks, W, H, 1280, 720)
+        post_exact = post_exact and n2 == ne and np.array_equal(j2[:n2], je[:ne])
     tot = _parity.merge(reps)
     tot["map_max_err"] = map_err
+    tot["post_on_engine_maps_bit_exact"] = bool(post_exact)
     tot["units"] = "x, y in display pixels (1280x720); scores and map errors for maps normalised to a maximum of 1"
     tot["reference"] = "CPU oracle, fp32 conv stack -> ImResize -> Nms -> connectLimbs*, same synthetic weights and frames"
-    tot["verdict"] = "pass" if (tot["people_matched"] == tot["people_ref"] == tot["people_engine"] and map_err <= 1e-3) else (
-        "numeric pass, set differs" if (tot["max_dc"] <= 1e-3 and map_err <= 1e-3) else "FAIL")
+    numeric = tot["max_dc"] <= 1e-3 and tot["max_dx_px"] <= 1.0 and tot["max_dy_px"] <= 1.0 and map_err <= 1e-3 and post_exact
+    tot["verdict"] = "FAIL" if not numeric else ("pass" if tot["people_matched"] == tot["people_ref"] == tot["people_engine"] else
+                                                 "numeric pass; people sets differ by near-tie compares on the synthetic noise maps (joints_structural)")
     return tot
 
 
@@ -242,8 +251,10 @@ def main():
                          "north-star tolerance (+-1e-3 on maps normalised to 1, tests/test_precision.py); fp16 = single-pass everywhere (2x outside it); "
                          "f16x3 = every layer as three fp16 passes; fp32 = exact-f32 MFMA")
     ap.add_argument("--split_layers", default=None, help="override the split set of --precision mixed (rtp_config.split_layers syntax)")
-    ap.add_argument("--in_flight", type=int, default=8)
-    ap.add_argument("--batch_frames", type=int, default=2, help="frames whose conv stacks share one launch sequence (1 = the reference's one frame per Forward)")
+    ap.add_argument("--in_flight", type=int, default=None, help="frames in flight per GPU (default 8; 10 for MPI = two batches of 5)")
+    ap.add_argument("--batch_frames", type=int, default=None, help="frames whose conv stacks share one launch sequence (1 = the reference's one frame per Forward); "
+                    "default 2 for COCO 656x368 (248 workgroups per 1/8-resolution launch), 5 for MPI 496x368 (240 workgroups of 128x128 tiles)")
+
     ap.add_argument("--model", default="coco", choices=["coco", "mpi"], help="coco = BASELINE configs[1..3] (656x368); mpi = configs[4] (15 parts, 496x368)")
     ap.add_argument("--exec", dest="exec_mode", default="graph", choices=["graph", "eager"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -251,6 +262,10 @@ def main():
     ap.add_argument("--no_parity", action="store_true", help="skip the people-level parity verdict against the CPU oracle chain (3 frames)")
     ap.add_argument("--dry_dispatch", action="store_true", help="self-test of the multi-rank plumbing without a GPU (gloo, no engine): tests/test_bench_spawn.py")
     args = ap.parse_args()
+    if args.batch_frames is None:
+        args.batch_frames = 5 if args.model == "mpi" else 2
+    if args.in_flight is None:
+        args.in_flight = 10 if args.model == "mpi" else 8
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_launcher(args))

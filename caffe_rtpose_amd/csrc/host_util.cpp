@@ -1,5 +1,6 @@
 // host_util.cpp — the host-only pieces of the path behind the C-ABI: model descriptor tables,
 // default thresholds, process_and_pad_image and the JSON body.  No GPU needed.
+#include <charconv>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -72,32 +73,37 @@ int rtp_process_and_pad_image(float* target, const unsigned char* bgr, int ow, i
   return RTP_OK;
 }
 
-// displayFrame's JSON body, rtpose.cpp:1394-1415: std::ofstream at default precision.
+// displayFrame's JSON body, rtpose.cpp:1394-1415: std::ofstream at default precision, i.e. every number as printf("%g")
+// (floatfield unset, precision 6).  std::to_chars(general, 6) is specified to produce exactly that text and costs a quarter of
+// an ostream insertion: 76 people x 54 numbers (the noise-map worst case) took 1.2 ms per frame through std::ostringstream —
+// one writer thread would have capped an 8-GPU node at ~800 frames/s.  tests/test_ref_golden.py: byte-identical to the
+// reference's own block, edge values included.
 long rtp_format_json(char* buf, size_t buflen, const float* joints, int num_people, int num_parts, float frame_scale) {
   if (!buf || (num_people > 0 && !joints) || num_people < 0 || num_parts <= 0) return RTP_EINVAL;
-  std::ostringstream fs;
   const double scale = 1.0 / frame_scale;
-  fs << "{\n";
-  fs << "\"version\":0.1,\n";
-  fs << "\"bodies\":[\n";
-  for (int ip = 0; ip < num_people; ip++) {
-    fs << "{\n" << "\"joints\":" << "[";
-    for (int ij = 0; ij < num_parts; ij++) {
-      fs << scale * joints[ip * num_parts * 3 + ij * 3 + 0] << ",";
-      fs << scale * joints[ip * num_parts * 3 + ij * 3 + 1] << ",";
-      fs << joints[ip * num_parts * 3 + ij * 3 + 2];
-      if (ij < num_parts - 1) fs << ",";
+  char* p = buf;
+  char* const end = buf + buflen;
+  auto lit = [&](const char* s) { const size_t n = strlen(s); if ((size_t)(end - p) < n + 1) return false; memcpy(p, s, n); p += n; return true; };
+  auto num = [&](double v) {
+    if (end - p < 40) return false;
+    const std::to_chars_result r = std::to_chars(p, end - 1, v, std::chars_format::general, 6);
+    if (r.ec != std::errc()) return false;
+    p = r.ptr;
+    return true;
+  };
+  bool ok = lit("{\n\"version\":0.1,\n\"bodies\":[\n");
+  for (int ip = 0; ok && ip < num_people; ip++) {
+    ok = lit("{\n\"joints\":[");
+    for (int ij = 0; ok && ij < num_parts; ij++) {
+      const float* j = joints + ((size_t)ip * num_parts + ij) * 3;
+      ok = num(scale * j[0]) && lit(",") && num(scale * j[1]) && lit(",") && num((double)j[2]) && (ij == num_parts - 1 || lit(","));
     }
-    fs << "]\n";
-    fs << "}";
-    if (ip < num_people - 1) fs << ",\n";
+    ok = ok && lit("]\n}") && (ip == num_people - 1 || lit(",\n"));
   }
-  fs << "]\n";
-  fs << "}\n";
-  const std::string s = fs.str();
-  if (s.size() + 1 > buflen) return RTP_ERANGE;
-  memcpy(buf, s.c_str(), s.size() + 1);
-  return (long)s.size();
+  ok = ok && lit("]\n}\n");
+  if (!ok) return RTP_ERANGE;
+  *p = 0;
+  return (long)(p - buf);
 }
 
 }  // extern "C"

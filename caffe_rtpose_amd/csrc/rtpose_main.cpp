@@ -56,6 +56,14 @@ struct Flags {
   unsigned long long synthetic_seed = 1;
   std::string devices;           // "0,0,1": device of worker i (default start_device + i); lets two workers share one GPU
   int test_worker_delay_ms = 0;  // test hook: every worker sleeps this long after a submit (provokes the >0.1 s frame drops)
+  // --dry_engine RATE: no GPU.  Every worker is a stand-in that copies the frame like rtp_submit_frame's staging copy and
+  // completes frames at RATE frames/s (pipelined, frames_in_flight deep) with --dry_people fake people each: the host side of
+  // --num_gpu N (producer -> queue -> workers -> re-orderer -> writer) can be driven at N x the measured per-GPU rate on any box.
+  double dry_engine = 0;
+  int dry_people = 5;
+  int producer_threads = 0;      // frames are generated / decoded ahead by this many threads (0 = hardware threads / 4, clamped to [2, 16])
+  int json_writers = -1;         // JSON files are written by this many threads (0 = by the display/writer thread itself, like the reference;
+                                 // default: 1 thread per 2 workers — creating a file costs the one display thread ~0.5 ms, 1600 frames/s at most)
 };
 
 int parse_flags(int argc, char** argv, Flags& F) {
@@ -64,8 +72,8 @@ int parse_flags(int argc, char** argv, Flags& F) {
       {"net_resolution", &F.net_resolution}, {"camera_resolution", &F.camera_resolution}, {"precision", &F.precision}, {"model", &F.model}, {"devices", &F.devices}};
   std::map<std::string, int*> iflags = {{"part_to_show", &F.part_to_show}, {"camera", &F.camera}, {"start_frame", &F.start_frame},
       {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}, {"batch_frames", &F.batch_frames},
-      {"test_worker_delay_ms", &F.test_worker_delay_ms}};
-  std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}};
+      {"test_worker_delay_ms", &F.test_worker_delay_ms}, {"dry_people", &F.dry_people}, {"json_writers", &F.json_writers}, {"producer_threads", &F.producer_threads}};
+  std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}, {"dry_engine", &F.dry_engine}};
   std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"host_preprocess", &F.host_preprocess}, {"no_display", &F.no_display},
       {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}};
   for (int i = 1; i < argc; ++i) {
@@ -106,7 +114,11 @@ void usage() {
          "  --resolution WxH (1280x720) --net_resolution WxH (656x368) --num_scales N (1) --scale_gap G (0.3) --start_scale S (1)\n"
          "  --num_gpu N (1) --start_device D (0) --no_frame_drops --write_json DIR --write_frames DIR --start_frame N\n"
          "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision mixed|fp16|f16x3|fp32 --frames_in_flight K --batch_frames B --host_preprocess\n"
-         "   --devices d0,d1,.. (device of each worker; the same device may appear twice)]\n");
+         "   --devices d0,d1,.. (device of each worker; the same device may appear twice)\n"
+         "   --dry_engine RATE (no GPU: every worker is a stand-in finishing RATE frames/s; measures the host side of --num_gpu N) --dry_people P\n"
+         "   --json_writers K (JSON files written by K threads instead of the one display thread) --producer_threads K (decode / generate ahead)]\n"
+         "  --write_frames draws the pose overlay only: the FPS / people-count text of the reference (cv::putText, rtpose.cpp:1319-1333) is not\n"
+         "  drawn, i.e. --no_text is implied.\n");
 }
 
 // ---- queues (caffe::BlockingQueue, util/blocking_queue.cpp:26-61) -----------------------------
@@ -153,6 +165,9 @@ struct Global {
   std::vector<int> per_worker;  // frames each worker submitted (dynamic pull from the one shared queue)
   std::atomic<int> workers_ready{0};  // workers start pulling once EVERY engine is up (engine creation takes seconds, short inputs milliseconds)
   std::atomic<bool> producer_done{false};
+  double first_commit = 0, last_written = 0;  // steady-state window: first frame committed .. last frame written
+  BlockingQueue<Frame> json_queue;             // --json_writers K
+  std::atomic<bool> json_done{false};
   int num_parts = 18;
   std::vector<std::string> image_list;
 };
@@ -180,45 +195,79 @@ void producer() {
     for (int i = 0; i < F.start_frame; ++i) if (rtp_video_read(vid, skip.data(), skip.size()) != RTP_OK) break;  // CAP_PROP_POS_FRAMES, :411
   } else nframes = (int)G.image_list.size();
   std::vector<unsigned char> img;
-  // --image_dir: files are decoded a few ahead on other threads (a 720p JPEG takes ~13 ms on one core);
-  // the producer still hands the frames over in file order, like the reference's single loop
+  // --image_dir files and synthetic frames are produced a few ahead by a small pool (a 720p JPEG takes ~13 ms on one core, a
+  // synthetic frame ~1 ms; 8 GPUs at 1 scale want ~8000 frames/s); the producer still hands the frames over in index order,
+  // like the reference's single loop.  Video files are read sequentially (one decoder state).
   struct Decoded { std::vector<unsigned char> bgr; int w = 0, h = 0; std::string err; };
-  std::deque<std::future<Decoded>> ahead;
-  const int decode_ahead = std::max(2, std::min(16, (int)std::thread::hardware_concurrency() / 4));  // 13 ms per 720p JPEG and core
-  int next_to_decode = F.start_frame;
-  auto decode_file = [](std::string path) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int pool_n = (synthetic || vid == nullptr) ? (F.producer_threads > 0 ? std::min(F.producer_threads, 64) : std::max(2, std::min(16, hw / 4))) : 0;
+  const int window = 4 * std::max(pool_n, 1);
+  std::mutex pm;
+  std::condition_variable pcv;
+  std::map<int, Decoded> ready;            // frame index -> frame, filled by the pool
+  int next_job = F.start_frame, consumed = F.start_frame;
+  bool pool_quit = false;
+  auto make_frame = [&](int fi) {
     Decoded d;
-    if (rtp_load_image(path.c_str(), nullptr, 0, &d.w, &d.h) != RTP_OK) { d.err = rtp_codec_last_error(); d.w = 0; return d; }
-    d.bgr.resize((size_t)d.w * d.h * 3);
-    if (rtp_load_image(path.c_str(), d.bgr.data(), d.bgr.size(), &d.w, &d.h) != RTP_OK) { d.err = rtp_codec_last_error(); d.w = 0; }
+    if (synthetic) {
+      d.w = sw; d.h = sh;
+      d.bgr.resize((size_t)sw * sh * 3);
+      rtp_synth_frame(d.bgr.data(), sw, sh, fi, seed);
+    } else {
+      const std::string& path = G.image_list[fi];
+      if (rtp_load_image(path.c_str(), nullptr, 0, &d.w, &d.h) != RTP_OK) { d.err = rtp_codec_last_error(); d.w = 0; return d; }
+      d.bgr.resize((size_t)d.w * d.h * 3);
+      if (rtp_load_image(path.c_str(), d.bgr.data(), d.bgr.size(), &d.w, &d.h) != RTP_OK) { d.err = rtp_codec_last_error(); d.w = 0; }
+    }
     return d;
   };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < pool_n; ++t)
+    pool.emplace_back([&]() {
+      while (true) {
+        int fi;
+        {
+          std::unique_lock<std::mutex> l(pm);
+          pcv.wait(l, [&] { return pool_quit || (next_job < nframes && next_job < consumed + window); });
+          if (pool_quit) return;
+          fi = next_job++;
+        }
+        Decoded d = make_frame(fi);
+        { std::lock_guard<std::mutex> l(pm); ready[fi] = std::move(d); }
+        pcv.notify_all();
+      }
+    });
   while (G.workers_ready.load() < F.num_gpu && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));  // no frame ages while the engines start
   for (int fi = F.start_frame; fi < nframes && !G.quit_threads; ++fi) {
-    // back-pressure (rtpose.cpp:311, 424-429)
-    while (G.input_queue.size() > 10 && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    // back-pressure (rtpose.cpp:311, 424-429); the queue bound follows the number of consumers
+    while ((int)G.input_queue.size() > 10 + 4 * F.num_gpu && !G.quit_threads) std::this_thread::sleep_for(std::chrono::microseconds(200));
     Frame fr;
     int w = sw, h = sh;
-    if (synthetic) {
-      img.resize((size_t)w * h * 3);
-      rtp_synth_frame(img.data(), w, h, fi, seed);
-      char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm;
-    } else if (vid) {
+    if (vid) {
       img.resize((size_t)w * h * 3);
       const int rc = rtp_video_read(vid, img.data(), img.size());
       if (rc == RTP_EAGAIN) break;  // end of the stream
       if (rc != RTP_OK) { fprintf(stderr, "video frame %d: %s\n", fi, rtp_codec_last_error()); break; }
       char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm;
     } else {
-      const std::string& path = G.image_list[fi];
-      while (next_to_decode < nframes && (int)ahead.size() < decode_ahead) ahead.push_back(std::async(std::launch::async, decode_file, G.image_list[next_to_decode++]));
-      Decoded d = ahead.front().get();
-      ahead.pop_front();
-      if (d.w == 0) { fprintf(stderr, "cannot decode %s: %s\n", path.c_str(), d.err.c_str()); continue; }
+      Decoded d;
+      {
+        std::unique_lock<std::mutex> l(pm);
+        pcv.wait(l, [&] { return ready.count(fi) != 0; });
+        d = std::move(ready[fi]);
+        ready.erase(fi);
+        consumed = fi + 1;
+      }
+      pcv.notify_all();
+      if (d.w == 0) { fprintf(stderr, "cannot decode %s: %s\n", G.image_list[fi].c_str(), d.err.c_str()); continue; }
       img.swap(d.bgr);
       w = d.w; h = d.h;
-      size_t sl = path.find_last_of('/'), dot = path.find_last_of('.');
-      fr.stem = path.substr(sl == std::string::npos ? 0 : sl + 1, dot - (sl == std::string::npos ? 0 : sl + 1));
+      if (synthetic) { char nm[64]; snprintf(nm, sizeof nm, "frame%06d", fi); fr.stem = nm; }
+      else {
+        const std::string& path = G.image_list[fi];
+        size_t sl = path.find_last_of('/'), dot = path.find_last_of('.');
+        fr.stem = path.substr(sl == std::string::npos ? 0 : sl + 1, dot - (sl == std::string::npos ? 0 : sl + 1));
+      }
     }
     fr.commit_time = wall();
     if (F.host_preprocess) {
@@ -228,16 +277,21 @@ void producer() {
         continue;
       }
     } else {
-      fr.image = img;
+      fr.image = std::move(img);   // handed over, not copied (2.76 MB per 720p frame)
+      img.clear();
       fr.img_w = w;
       fr.img_h = h;
     }
     fr.index = global_counter++;
     fr.video_frame_number = fi;
     fr.preprocessed_time = wall();
+    if (G.first_commit == 0) G.first_commit = fr.commit_time;
     G.produced++;
     G.input_queue.push(std::move(fr));
   }
+  { std::lock_guard<std::mutex> l(pm); pool_quit = true; }
+  pcv.notify_all();
+  for (auto& t : pool) t.join();
   if (vid) rtp_video_close(vid);
   G.producer_done = true;
 }
@@ -258,16 +312,46 @@ void worker(int widx, int device, int* status) {
   cfg.batch_frames = F.batch_frames;
   cfg.render = F.write_frames.empty() ? 0 : 1 + F.part_to_show;  // render() of rtpose.cpp:270-299: pose overlay or a --part_to_show view
   rtp_engine* e = nullptr;
-  if (rtp_engine_create(&cfg, &e) != RTP_OK) {
+  const bool dry = F.dry_engine > 0;
+  if (!dry && rtp_engine_create(&cfg, &e) != RTP_OK) {
     fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));
     *status = 1;
     G.quit_threads = true;
     return;
   }
-  int num_parts = 18;
-  rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
+  int num_parts = F.model == "mpi" ? 15 : 18;
+  if (!dry) rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
   G.num_parts = num_parts;
-  fprintf(stderr, "GPU %d is ready\n", device);
+  // --dry_engine: what the engine costs the HOST per frame (the staging copy of rtp_submit_frame, the joints copy of
+  // rtp_collect) and when a frame completes (RATE frames/s, at least two frame times after its submit)
+  std::vector<unsigned char> dry_staging;
+  std::deque<double> dry_done;   // completion times of the frames in flight
+  double dry_last = 0;
+  auto dry_submit = [&](const Frame& fr) {
+    const size_t n = F.host_preprocess ? fr.data.size() * sizeof(float) : fr.image.size();
+    if (dry_staging.size() < n) dry_staging.resize(n);
+    memcpy(dry_staging.data(), F.host_preprocess ? (const void*)fr.data.data() : (const void*)fr.image.data(), n);
+    const double now = wall();
+    dry_last = std::max(now + 2.0 / F.dry_engine, dry_last + 1.0 / F.dry_engine);
+    dry_done.push_back(dry_last);
+    return RTP_OK;
+  };
+  auto dry_collect = [&](const Frame& fr, float* joints, int* n) {
+    const double t = dry_done.front();
+    dry_done.pop_front();
+    for (double now = wall(); now < t; now = wall()) std::this_thread::sleep_for(std::chrono::duration<double>(std::min(t - now, 0.0005)));
+    const int P = std::max(0, std::min(F.dry_people, (int)RTP_MAX_PEOPLE));
+    unsigned long long r = 0x9E3779B97F4A7C15ull * (unsigned long long)(fr.index + 1);
+    for (int i = 0; i < P * num_parts; ++i) {
+      r ^= r << 13; r ^= r >> 7; r ^= r << 17;
+      joints[3 * i] = (float)(r % 1280000) / 1000.f;
+      joints[3 * i + 1] = (float)((r >> 20) % 720000) / 1000.f;
+      joints[3 * i + 2] = (float)((r >> 40) % 1000) / 1000.f;
+    }
+    *n = P;
+    return RTP_OK;
+  };
+  fprintf(stderr, dry ? "dry worker %d is ready (%.0f frames/s)\n" : "GPU %d is ready\n", device, F.dry_engine);
   G.workers_ready++;
   while (G.workers_ready.load() < F.num_gpu && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   std::deque<Frame> inflight;
@@ -278,8 +362,9 @@ void worker(int widx, int device, int* status) {
     Frame fr = std::move(inflight.front());
     inflight.pop_front();
     if (!F.write_frames.empty()) fr.rendered.resize((size_t)DISP_W * DISP_H * 3);
-    const int rc = F.write_frames.empty() ? rtp_collect(e, &tag, joints.data(), &n)
-                                          : rtp_collect_rendered(e, &tag, joints.data(), &n, fr.rendered.data());
+    const int rc = dry ? dry_collect(fr, joints.data(), &n)
+                       : F.write_frames.empty() ? rtp_collect(e, &tag, joints.data(), &n)
+                                                : rtp_collect_rendered(e, &tag, joints.data(), &n, fr.rendered.data());
     if (rc != RTP_OK) { fprintf(stderr, "GPU %d frame %d: %s\n", device, fr.index, rtp_last_error(e)); n = 0; }
     fr.numPeople = n;
     fr.joints.assign(joints.begin(), joints.begin() + (size_t)n * num_parts * 3);
@@ -299,8 +384,10 @@ void worker(int widx, int device, int* status) {
         G.dropped++;
         continue;
       }
-      const int src = F.host_preprocess ? rtp_submit(e, fr.data.data(), (uint64_t)fr.index)
-                                        : rtp_submit_frame(e, fr.image.data(), fr.img_w, fr.img_h, (uint64_t)fr.index, &fr.scale);
+      if (dry && !F.host_preprocess) fr.scale = (float)rtp_display_fit_scale(fr.img_w, fr.img_h, DISP_W, DISP_H);
+      const int src = dry ? dry_submit(fr)
+                          : F.host_preprocess ? rtp_submit(e, fr.data.data(), (uint64_t)fr.index)
+                                              : rtp_submit_frame(e, fr.image.data(), fr.img_w, fr.img_h, (uint64_t)fr.index, &fr.scale);
       fr.image.clear();
       fr.image.shrink_to_fit();
       if (src != RTP_OK) {  // nobody else may be left to drain the queue: stop the producer too
@@ -319,7 +406,7 @@ void worker(int widx, int device, int* status) {
     else std::this_thread::sleep_for(std::chrono::microseconds(200));
   }
   while (!inflight.empty()) collect_one();
-  rtp_engine_destroy(e);
+  if (e) rtp_engine_destroy(e);
 }
 
 // ---- re-orderer (buffer_and_order, rtpose.cpp:1214-1273) ---------------------------------------------
@@ -376,6 +463,33 @@ void encoder() {
   }
 }
 
+// the JSON block of displayFrame (rtpose.cpp:1383-1416)
+void write_json_file(const Frame& fr, std::vector<char>& buf) {
+  char fname[1024];
+  if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.json", F.write_json.c_str(), fr.video_frame_number);  // :1388
+  else snprintf(fname, sizeof fname, "%s/%s.json", F.write_json.c_str(), fr.stem.c_str());                                   // :1390-1393
+  const long n = rtp_format_json(buf.data(), buf.size(), fr.joints.data(), fr.numPeople, G.num_parts, fr.scale);
+  if (n >= 0) {
+    FILE* f = fopen(fname, "wb");
+    if (f) { fwrite(buf.data(), 1, (size_t)n, f); fclose(f); }
+    else fprintf(stderr, "cannot create %s\n", fname);
+  } else fprintf(stderr, "JSON buffer too small for frame %d\n", fr.index);
+}
+// --json_writers K: the files are independent (named by frame number / image stem), so K threads format and write them;
+// ordering is still the re-orderer's (what the display thread shows / logs)
+void json_writer() {
+  std::vector<char> buf(1 << 20);
+  while (true) {
+    Frame fr;
+    if (!G.json_queue.try_pop(&fr)) {
+      if (G.json_done.load() && G.json_queue.size() == 0) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
+    }
+    write_json_file(fr, buf);
+  }
+}
+
 // ---- writer (displayFrame, rtpose.cpp:1315-1454) -------------------------------------------------------
 void writer(std::atomic<bool>* reorder_done) {
   int counter = 1;
@@ -388,14 +502,8 @@ void writer(std::atomic<bool>* reorder_done) {
       std::this_thread::sleep_for(std::chrono::microseconds(200));
       continue;
     }
-    if (!F.write_json.empty()) {
-      char fname[1024];
-      if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.json", F.write_json.c_str(), fr.video_frame_number);  // :1388
-      else snprintf(fname, sizeof fname, "%s/%s.json", F.write_json.c_str(), fr.stem.c_str());                                   // :1390-1393
-      const long n = rtp_format_json(buf.data(), buf.size(), fr.joints.data(), fr.numPeople, G.num_parts, fr.scale);
-      if (n >= 0) { std::ofstream fs(fname, std::ios::binary); fs.write(buf.data(), n); }
-      else fprintf(stderr, "JSON buffer too small for frame %d\n", fr.index);
-    }
+    double t_commit = fr.commit_time, t_pre = fr.preprocessed_time, t_fetch = fr.gpu_fetched_time, t_done = fr.gpu_computed_time, t_b0 = fr.buffer_start_time, t_b1 = fr.buffer_end_time;
+    const int f_index = fr.index, f_np = fr.numPeople;
     if (!F.write_frames.empty() && !fr.rendered.empty()) {  // cv::imwrite(fname, wrap_frame, {JPEG_QUALITY, 98}), rtpose.cpp:1367-1381
       char fname[1024];
       if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.jpg", F.write_frames.c_str(), fr.video_frame_number);
@@ -403,16 +511,21 @@ void writer(std::atomic<bool>* reorder_done) {
       while (G.encode_queue.size() > 32) std::this_thread::sleep_for(std::chrono::milliseconds(1));  // back-pressure on the encoders
       G.encode_queue.push(EncodeJob{fname, std::move(fr.rendered)});
     }
+    if (!F.write_json.empty()) {
+      if (F.json_writers > 0) {
+        while (G.json_queue.size() > 256) std::this_thread::sleep_for(std::chrono::microseconds(200));  // back-pressure on the JSON writers
+        G.json_queue.push(std::move(fr));
+      } else write_json_file(fr, buf);
+    }
     G.finished++;
+    G.last_written = wall();
     counter++;
     if (counter % 30 == 0) {  // rtpose.cpp:1421-1441
       const double now = wall();
       const double fps = 30.0 / (now - last_time);
       last_time = now;
       fprintf(stderr, "# %d, NP %d, Latency %.3f, Preprocess %.3f, QueueA %.3f, GPU %.3f, QueueB %.3f, Buffered %.3f, QueueD %.3f, FPS = %.1f\n",
-              fr.index, fr.numPeople, now - fr.commit_time, fr.preprocessed_time - fr.commit_time, fr.gpu_fetched_time - fr.preprocessed_time,
-              fr.gpu_computed_time - fr.gpu_fetched_time, fr.buffer_start_time - fr.gpu_computed_time, fr.buffer_end_time - fr.buffer_start_time,
-              now - fr.buffer_end_time, fps);
+              f_index, f_np, now - t_commit, t_pre - t_commit, t_fetch - t_pre, t_done - t_fetch, t_b0 - t_done, t_b1 - t_b0, now - t_b1, fps);
     }
   }
 }
@@ -468,6 +581,9 @@ int main(int argc, char** argv) {
   if (F.precision != "mixed" && F.precision != "fp16" && F.precision != "f16x3" && F.precision != "fp32") { fprintf(stderr, "--precision must be mixed, fp16, f16x3 or fp32\n"); return 1; }
   if (F.frames_in_flight < 1 || F.frames_in_flight > 64) { fprintf(stderr, "--frames_in_flight must be in [1, 64]\n"); return 1; }
   if (F.batch_frames < 1 || F.batch_frames > 16) { fprintf(stderr, "--batch_frames must be in [1, 16]\n"); return 1; }
+  if (F.json_writers < 0) F.json_writers = (F.num_gpu + 1) / 2;
+  if (F.dry_engine < 0 || F.json_writers > 64) { fprintf(stderr, "--dry_engine must be >= 0 and --json_writers in [0, 64]\n"); return 1; }
+  if (F.dry_engine > 0 && !F.write_frames.empty()) { fprintf(stderr, "--dry_engine has no renderer: drop --write_frames\n"); return 1; }
   std::vector<int> devs;
   for (int g = 0; g < F.num_gpu; ++g) devs.push_back(g + F.start_device);  // rtpose.cpp:1466
   if (!F.devices.empty()) {
@@ -494,6 +610,8 @@ int main(int argc, char** argv) {
   std::thread prod(producer), reo(reorderer, &workers_done), wr(writer, &reorder_done);
   std::vector<std::thread> encoders;
   if (!F.write_frames.empty()) for (int i = 0; i < 8; ++i) encoders.emplace_back(encoder);
+  std::vector<std::thread> jsonw;
+  if (!F.write_json.empty()) for (int i = 0; i < F.json_writers; ++i) jsonw.emplace_back(json_writer);
   prod.join();
   for (auto& t : workers) t.join();
   workers_done = true;
@@ -502,11 +620,14 @@ int main(int argc, char** argv) {
   wr.join();
   G.encode_done = true;
   for (auto& t : encoders) t.join();
+  G.json_done = true;
+  for (auto& t : jsonw) t.join();
   int rc = 0;
   for (int s : status) rc |= s;
   const double dt = wall() - t0;
   for (int g = 0; g < F.num_gpu; ++g) fprintf(stderr, "worker %d (GPU %d) processed %d frames\n", g, devs[g], G.per_worker[g]);
-  fprintf(stderr, "rtcpm %s. Total time: %.3f seconds. frames produced %d, written %d, dropped %d (%.1f FPS incl. init)\n",
-          rc ? "FAILED" : "successfully finished", dt, G.produced.load(), G.finished.load(), G.dropped.load(), G.finished.load() / dt);
+  const double steady = (G.finished.load() > 1 && G.last_written > G.first_commit) ? G.finished.load() / (G.last_written - G.first_commit) : 0.0;
+  fprintf(stderr, "rtcpm %s. Total time: %.3f seconds. frames produced %d, written %d, dropped %d (%.1f FPS incl. init, %.1f FPS first frame committed -> last frame written)\n",
+          rc ? "FAILED" : "successfully finished", dt, G.produced.load(), G.finished.load(), G.dropped.load(), G.finished.load() / dt, steady);
   return rc;
 }
