@@ -34,6 +34,7 @@ class rtp_config(C.Structure):
         ("render", C.c_int),
         ("exec_mode", C.c_int),
         ("split_layers", C.c_char_p),
+        ("keep_blobs", C.c_int),
     ]
 
 

@@ -70,6 +70,73 @@ __device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntil
   return b;
 }
 
+// One pixel x 16 channels of finished values (bias and ReLU applied) to every destination tensor of the problem: the value as T,
+// its rounding error as a lo block and / or as fp8 compensation operands where the destination carries them.
+template <typename T>
+__device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix, int c0, const float (&v)[16]) {
+  constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
+  const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
+  T out[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) out[u] = (T)v[u];
+  for (int d = 0; d < pr.ndst; ++d) {
+    T* dp = (T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].coff + c0;
+    const bool vec_ok = nvalid == 16 && (((size_t)dp) & 15) == 0;
+    if (vec_ok) {
+#pragma unroll
+      for (int u = 0; u < 16 / VEC; ++u) {
+        uint4 pk;
+        __builtin_memcpy(&pk, &out[u * VEC], 16);
+        ((uint4*)dp)[u] = pk;
+      }
+    } else {
+      for (int u = 0; u < nvalid; ++u) dp[u] = out[u];
+    }
+    if (pr.dst[d].lo_off) {  // split-precision consumer: the rounding error of the stored value, as a second T
+      T lo[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) lo[u] = (T)(v[u] - (float)out[u]);
+      T* lp = dp + pr.dst[d].lo_off;
+      if (vec_ok && (((size_t)lp) & 15) == 0) {
+#pragma unroll
+        for (int u = 0; u < 16 / VEC; ++u) {
+          uint4 pk;
+          __builtin_memcpy(&pk, &lo[u * VEC], 16);
+          ((uint4*)lp)[u] = pk;
+        }
+      } else {
+        for (int u = 0; u < nvalid; ++u) lp[u] = lo[u];
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      if (pr.dst[d].q_off) {  // fp8 compensation operands for a consumer that runs the fp8 passes
+        const int ch = pr.dst[d].coff + c0;
+        unsigned char* qrow = (unsigned char*)((T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].q_off);
+        float lof[16], hif[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { hif[u] = (float)out[u]; lof[u] = (v[u] - hif[u]) * (float)(1 << Q_LO_EXP); hif[u] *= (float)(1 << Q_HI_EXP); }
+        if (nvalid == 16 && (ch & 15) == 0) {
+          unsigned char* qb = qrow + (ch >> 6) * 128 + (ch & 63);
+          uint4 ql, qh;
+          ql.x = pack4_fp8(lof[0], lof[1], lof[2], lof[3]); ql.y = pack4_fp8(lof[4], lof[5], lof[6], lof[7]);
+          ql.z = pack4_fp8(lof[8], lof[9], lof[10], lof[11]); ql.w = pack4_fp8(lof[12], lof[13], lof[14], lof[15]);
+          qh.x = pack4_fp8(hif[0], hif[1], hif[2], hif[3]); qh.y = pack4_fp8(hif[4], hif[5], hif[6], hif[7]);
+          qh.z = pack4_fp8(hif[8], hif[9], hif[10], hif[11]); qh.w = pack4_fp8(hif[12], hif[13], hif[14], hif[15]);
+          *(uint4*)qb = ql;
+          *(uint4*)(qb + 64) = qh;
+        } else {
+          for (int u = 0; u < nvalid; ++u) {
+            const int cu = ch + u;
+            unsigned char* qb = qrow + (cu >> 6) * 128 + (cu & 63);
+            qb[0] = (unsigned char)(pack4_fp8(lof[u], 0.f, 0.f, 0.f) & 0xff);
+            qb[64] = (unsigned char)(pack4_fp8(hif[u], 0.f, 0.f, 0.f) & 0xff);
+          }
+        }
+      }
+    }
+  }
+}
+
 // Epilogue: every wave dumps its fp32 accumulators into LDS as [kg][row][col] (the staging LDS is
 // dead: callers barrier first), then ALL 256 threads own (pixel row, 16-channel chunk) items: sum
 // the KSPLIT partials, add bias, ReLU, convert, and store 16 channels with 16-byte vector stores
@@ -132,71 +199,78 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
       }
     }
     const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
-    T out[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) out[u] = (T)v[u];
     const long pix = img_pix0 + m;
-    for (int d = 0; d < pr.ndst; ++d) {
-      T* dp = (T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].coff + c0;
-      const bool vec_ok = nvalid == 16 && (((size_t)dp) & 15) == 0;
-      if (vec_ok) {
-#pragma unroll
-        for (int u = 0; u < 16 / VEC; ++u) {
-          uint4 pk;
-          __builtin_memcpy(&pk, &out[u * VEC], 16);
-          ((uint4*)dp)[u] = pk;
-        }
-      } else {
-        for (int u = 0; u < nvalid; ++u) dp[u] = out[u];
-      }
-      if (pr.dst[d].lo_off) {  // split-precision consumer: the rounding error of the stored value, as a second T
-        T lo[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) lo[u] = (T)(v[u] - (float)out[u]);
-        T* lp = dp + pr.dst[d].lo_off;
-        if (vec_ok && (((size_t)lp) & 15) == 0) {
-#pragma unroll
-          for (int u = 0; u < 16 / VEC; ++u) {
-            uint4 pk;
-            __builtin_memcpy(&pk, &lo[u * VEC], 16);
-            ((uint4*)lp)[u] = pk;
-          }
-        } else {
-          for (int u = 0; u < nvalid; ++u) lp[u] = lo[u];
-        }
-      }
-      if constexpr (sizeof(T) == 2) {
-        if (pr.dst[d].q_off) {  // fp8 compensation operands for a consumer that runs the fp8 passes
-          const int ch = pr.dst[d].coff + c0;
-          unsigned char* qrow = (unsigned char*)((T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].q_off);
-          float lof[16], hif[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) { hif[u] = (float)out[u]; lof[u] = (v[u] - hif[u]) * (float)(1 << Q_LO_EXP); hif[u] *= (float)(1 << Q_HI_EXP); }
-          if (nvalid == 16 && (ch & 15) == 0) {
-            unsigned char* qb = qrow + (ch >> 6) * 128 + (ch & 63);
-            uint4 ql, qh;
-            ql.x = pack4_fp8(lof[0], lof[1], lof[2], lof[3]); ql.y = pack4_fp8(lof[4], lof[5], lof[6], lof[7]);
-            ql.z = pack4_fp8(lof[8], lof[9], lof[10], lof[11]); ql.w = pack4_fp8(lof[12], lof[13], lof[14], lof[15]);
-            qh.x = pack4_fp8(hif[0], hif[1], hif[2], hif[3]); qh.y = pack4_fp8(hif[4], hif[5], hif[6], hif[7]);
-            qh.z = pack4_fp8(hif[8], hif[9], hif[10], hif[11]); qh.w = pack4_fp8(hif[12], hif[13], hif[14], hif[15]);
-            *(uint4*)qb = ql;
-            *(uint4*)(qb + 64) = qh;
-          } else {
-            for (int u = 0; u < nvalid; ++u) {
-              const int cu = ch + u;
-              unsigned char* qb = qrow + (cu >> 6) * 128 + (cu & 63);
-              qb[0] = (unsigned char)(pack4_fp8(lof[u], 0.f, 0.f, 0.f) & 0xff);
-              qb[64] = (unsigned char)(pack4_fp8(hif[u], 0.f, 0.f, 0.f) & 0xff);
-            }
-          }
-        }
-      }
-    }
+    conv_store_pixel<T>(pr, pix, c0, v);
     if (pr.out_nchw) {
       float* op = pr.out_nchw + (((long)img * pr.out_C + pr.out_coff + c0) * P.H + y) * P.W + (xp - P.halo);
       const long plane = (long)P.H * P.W;
       for (int u = 0; u < nvalid; ++u) op[u * plane] = v[u];
     }
+  }
+}
+
+// Epilogue of a convolution whose only consumer is a 2x2 / stride-2 MAX pooling layer (pooling_layer.cpp:140-180, even
+// resolutions): the tile is TWO image rows x BM/2 pixels (conv_ring.hip, POOL), logical tile row r < BM/2 is pixel x0 + r of
+// row 2*pair and BM/2 + r the pixel below it, so every pooled pixel has its four inputs in this tile.  The maximum is taken on
+// the fp32 sums (after the KSPLIT reduction): bias add, ReLU and the conversions to T / lo / fp8 are monotone, so
+// max-then-convert stores exactly the bytes convert-then-pool stores (the stand-alone pooling kernel keeps the element with
+// the largest (hi, lo) pair, which is the element with the largest fp32 value).  Only the POOLED tensor is written.
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
+                                                   int kg, int wm0, int wn0, int lane, int img, int pair, int x0, int n0) {
+  static_assert(KSPLIT * BM * BN * 4 <= 64 * 1024, "partials fit in 64 KiB of LDS");
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  float* red = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+        const int col = wn0 + j * 32 + lrow;
+        red[(kg * BM + row) * BN + col] = acc[i][j][q];
+      }
+  __syncthreads();
+  constexpr int CHUNKS = BN / 16, HALF = BM / 2, ITEMS = (HALF / 2) * CHUNKS;
+  for (int item = threadIdx.x; item < ITEMS; item += 256) {
+    const int k = item / CHUNKS, chunk = item % CHUNKS;
+    int x = x0 + 2 * k;
+    const int np_ = x / P.pool_wq;   // the tile walked past the pitch: these columns belong to a later row pair (pitch and x0 are even)
+    x -= np_ * P.pool_wq;
+    const int pr_ = pair + np_;
+    const int c0 = n0 + chunk * 16;
+    if (pr_ >= P.H / 2 || x >= P.W || c0 >= pr.Cout) continue;
+    const long out_row = (long)img * P.pool_img_pix + (long)(pr_ + P.pool_halo) * P.pool_Wp + P.pool_halo;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // (0,0) (0,1) (1,0) (1,1)
+      const int row = (e >> 1) * HALF + 2 * k + (e & 1);
+      float t[16];
+      const floatx4* src = (const floatx4*)(red + row * BN + chunk * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const floatx4 w = src[u]; t[4 * u] = w[0]; t[4 * u + 1] = w[1]; t[4 * u + 2] = w[2]; t[4 * u + 3] = w[3]; }
+#pragma unroll
+      for (int k2 = 1; k2 < KSPLIT; ++k2) {
+        const floatx4* s2 = (const floatx4*)(red + (k2 * BM + row) * BN + chunk * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const floatx4 w = s2[u]; t[4 * u] += w[0]; t[4 * u + 1] += w[1]; t[4 * u + 2] += w[2]; t[4 * u + 3] += w[3]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (e == 0 || t[u] > v[u]) ? t[u] : v[u];
+    }
+    const floatx4* bsrc = (const floatx4*)(pr.bias + c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const floatx4 bb = bsrc[u];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        float t = v[4 * u + e2] + bb[e2];
+        if (P.relu) t = t > 0.f ? t : 0.f;
+        v[4 * u + e2] = t;
+      }
+    }
+    conv_store_pixel<T>(pr, out_row + (x >> 1), c0, v);
   }
 }
 

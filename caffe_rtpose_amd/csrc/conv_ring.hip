@@ -219,9 +219,15 @@ constexpr int ring_wait_count(int s) {
 //       read by lanes 31 / 63.  Only the first tap of a strip reads all A fragments from LDS: 6/7 (7x7) or 2/3 (3x3) of the A
 //       reads = 43 % / 33 % of all ds_read traffic disappear.  The ablation showed the launch is bound by the matrix pipe at a
 //       clock that drops when the LDS is busy (no ds_reads: 2.2 instead of 1.8 GHz); same MFMA order, bit-identical results.
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0, bool ILV = false>
+//   POOL: the convolution's only consumer is a 2x2 / stride-2 max pooling layer.  The M tile is TWO image rows x BM/2 pixels instead
+//       of BM consecutive flat pixels: LDS strip rows [0, BM/2+KS-1) hold the pixels of row 2*pair around x0 .. x0+BM/2-1, rows
+//       [BM/2+KS-1, 2*(BM/2+KS-1)) the same columns one image row below (only the per-lane DMA source offsets differ — they are
+//       loop-invariant anyway), wave row wm multiplies tile row wm, and the epilogue pools in LDS and writes only the pooled
+//       tensor (conv_common.h).  Tiles walk the (row pair, x) space with an EVEN pitch pool_wq >= W + pad, so x0 is always even.
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0, bool ILV = false, bool POOL = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvParams P) {
   static_assert(!ILV || SPEC, "interleaved fragment rows exist in the wave-specialised kernels only");
+  static_assert(!POOL || (!ILV && WM == 2 && BM == 128), "fused pooling: two wave rows, one per image row of the tile");
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
   constexpr int NCH = TR::NCH, GPW = TR::GPW, SB = TR::SB, RPI = TR::RPI;
   constexpr int A_PW = TR::A_PW, B_PW = TR::B_PW, TM = TR::TM, TN = TR::TN;
@@ -251,9 +257,17 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   const int n0 = bc.ntile * BN;
   const int nchunk = P.nchunk;
   const long pix_bytes = (long)P.in_cstride * (long)sizeof(T);
+  constexpr int PHALF = BM / 2 + KS - 1;  // POOL: LDS strip rows per image row of the tile
+  static_assert(!POOL || 2 * PHALF <= TR::AROWS, "both image rows of a pooled tile fit the strip buffer");
+  int pool_pair = 0, pool_x0 = 0;
+  if constexpr (POOL) {
+    const int q0 = bc.mtile * (BM / 2);
+    pool_pair = q0 / P.pool_wq;
+    pool_x0 = q0 - pool_pair * P.pool_wq;
+  }
   // strip (r, chunk) starts at a_ptr; consecutive strips: chunk += 1 (CHB bytes), then next filter row
   const unsigned char* a_ptr = (const unsigned char*)pr.in +
-      ((long)img * P.img_pix + (long)P.halo * P.Wp + m0 - (long)PAD * P.Wp - PAD) * pix_bytes;
+      ((long)img * P.img_pix + (long)P.halo * P.Wp + (POOL ? 2 * pool_pair * P.Wp : m0) - (long)PAD * P.Wp - PAD) * pix_bytes;
   const long row_step_bytes = (long)P.Wp * pix_bytes;
   // weights are packed in STEP order [r][chunk][s][CoutP][CHB]: the tile pointer just increments
   const long w_tile_stride = (long)P.CoutP * CHB;
@@ -266,7 +280,18 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     const int j = wave * A_PW + q;
     const int row = j * RPI + lane / NCH;
     const int cphys = lane % NCH;
-    a_voff[q] = (unsigned)(row * (int)pix_bytes + ((cphys ^ ring_swz_a<CHB, TR::TM, ILV>(row)) * 16) - (q & 3) * 1024);
+    int src_pix = row;  // pixel of LDS strip row `row`, relative to a_ptr
+    if constexpr (POOL) {
+      const int sel = row >= PHALF ? 1 : 0;
+      // x position in the (row pair, x) walk (real image columns; element (y, x) lives at padded column x + halo).  [0, W) are
+      // pixels; [W, pitch) are zero columns — the right halo of this pair and the left halo of the next one — served by the
+      // gap pixel that follows the row in memory; every further `pitch` positions = one row pair down.
+      const int a = pool_x0 - PAD + (row - sel * PHALF);
+      const int np_ = a >= 0 ? a / P.pool_wq : 0;
+      const int ar = a - np_ * P.pool_wq;
+      src_pix = np_ * 2 * P.Wp + (ar < P.W ? ar : P.W) + P.halo + PAD + sel * P.Wp;
+    }
+    a_voff[q] = (unsigned)(src_pix * (int)pix_bytes + ((cphys ^ ring_swz_a<CHB, TR::TM, ILV>(row)) * 16) - (q & 3) * 1024);
   }
   const unsigned b_voff = (unsigned)(wave * B_PW * 1024 + lane * 16);
   const unsigned sA_addr = lds_addr_of(sA) + wave * A_PW * 1024;
@@ -303,7 +328,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   const int brow0 = wn0 + lrow;
   const int bswz = ring_swz<CHB>(brow0);
   const unsigned char* pb_lane = sB + brow0 * CHB;
-  const int arow_base = wm0 + lrow;
+  const int arow_base = (POOL ? (wrem / WN) * PHALF : wm0) + lrow;
 
   uint4 fa[GPW][TM], fb[GPW][TN];      // fragments of the tap being multiplied
   uint4 na_[GPW][TM], nb_[GPW][TN];    // fragments of the tap being prefetched
@@ -551,7 +576,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     }
     wait_vmcnt<63>();
     __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
-    conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
+    if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0);
+    else conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
     if (P.clkprobe && tid == 0 && blockIdx.x == 0) {  // shader-clock cycles vs 100 MHz wall clock over this workgroup's life
       P.clkprobe[0] = clock64() - clk0;
       P.clkprobe[1] = wall_clock64() - wall0;
@@ -642,15 +668,26 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
+  if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0);
+  else conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
 }
 
 #ifndef RTP_RING_NO_LAUNCHERS  // (tools/ring_probe.hip instantiates single kernels to inspect their ISA)
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0, bool ILV = false>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR = 0, bool ILV = false, bool POOL = false>
 static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream);
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW = 1>
 static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStream_t stream) {
+  if (P.pool) {  // fused 2x2 max pooling: the 3x3 trunk layers in front of a pooling layer (fp16 storage, 128-pixel tiles, 128-byte chunks)
+    if constexpr (std::is_same<T, _Float16>::value && KS == 3 && BM == 128 && WM == 2 && CHB == 128) {
+      if (P.q_from > 0) {
+        if constexpr (((CHB / 32) / KSPLIT) % 2 == 0) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100, false, true>(P, nprob, N, stream);
+        else return hipErrorInvalidValue;
+      }
+      return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 0, false, true>(P, nprob, N, stream);
+    } else
+      return hipErrorInvalidValue;
+  }
   if (P.q_from > 0) {  // fp8-compensated layer: always the wave-specialised kernel, q instantiation
     if constexpr (std::is_same<T, _Float16>::value && ((CHB / 32) / KSPLIT) % 2 == 0) {
       if (P.ilv) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100, true>(P, nprob, N, stream);
@@ -682,10 +719,10 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
   return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, false>(P, nprob, N, stream);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR, bool ILV>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR, bool ILV, bool POOL>
 static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStream_t stream) {
   using TR = RingTraits<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_>;
-  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC, VAR, ILV>;
+  auto kern = conv_ring_kernel<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, SPEC, VAR, ILV, POOL>;
   static std::atomic<unsigned> attr_mask{0};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -52,6 +52,7 @@ struct Tensor {
   // split precision: [0, Cp) hi; need_lo: [Cp, 2Cp) lo = T(v - float(T(v))) (consumers running three fp16 passes);
   // need_q: a further Cp elements = 2*Cp bytes of fp8 compensation operands (consumers running the fp8 passes, ConvDst::q_off)
   bool need_lo = false, need_q = false;
+  bool written = true;      // false: the blob was fused away (a convolution pools in its epilogue and writes only the pooled tensor)
   int stride() const { return Cp * (1 + (need_lo ? 1 : 0) + (need_q ? 1 : 0)); }  // channels (elements) per pixel in memory
   int lo_off() const { return need_lo ? Cp : 0; }
   int q_off() const { return need_q ? Cp * (need_lo ? 2 : 1) : 0; }
@@ -79,6 +80,7 @@ struct ConvOp {
   int passes() const { return h8 ? 2 : 1 + (split_a ? 1 : 0) + (split_w ? 1 : 0); }  // in units of one fp16 pass of MFMA time
   int wrap_at() const { return h8 ? 0 : (split_w ? (split_a ? 2 * ncp : ncp) : 0); }
   int last_phys() const { return h8 ? ncp - 1 : (split_w ? ncp - 1 : (split_a ? 2 * ncp - 1 : ncp - 1)); }
+  int pool = -1;            // >= 0: this convolution's only consumer is pooling layer `pool`; it pools in its epilogue (conv_ring.hip POOL)
   int fused = 0;            // 1 / 2: first / second 1x1 of a conv_pw2 step (weights packed for that kernel)
   int fused_chunks = 0;     // middle channels / 128
   size_t w_off = 0, b_off = 0, w_bytes = 0;
@@ -564,6 +566,28 @@ int build_plan(rtp_engine* e) {
     if (e->tensors[e->pools[pi].out_tensor].need_lo) e->tensors[e->pools[pi].in_tensor].need_lo = true;
     if (e->tensors[e->pools[pi].out_tensor].need_q) e->tensors[e->pools[pi].in_tensor].need_q = true;
   }
+  // 2x2 max pooling inside the producing convolution's epilogue: the pooling layer's input blob has no other consumer, the layer
+  // runs on a ring kernel with 128-pixel tiles of 128-byte chunks (the trunk's conv1_2 / conv2_2 / conv3_4), even resolution.
+  // The un-pooled blob is then never written (rtp_config.keep_blobs = 1 keeps every blob tappable and pools in its own launch).
+  {
+    static const char* fp = getenv("RTP_FUSE_POOL");  // experiments: 0 = stand-alone pooling launches
+    for (size_t si = 1; si < e->steps.size() && !e->cfg.keep_blobs && !(fp && fp[0] == '0'); ++si) {
+      if (e->steps[si].type != 2 || e->steps[si - 1].type != 1 || e->steps[si - 1].b >= 0) continue;
+      const int pi = e->steps[si].a;
+      ConvOp& A = e->convs[e->steps[si - 1].a];
+      const PoolOp& po = e->pools[pi];
+      const Geom& g = e->geom[A.level];
+      bool ok = e->prec == 0 && A.impl == 1 && A.k_eff == 3 && A.rowb == 128 && (A.cfg == CFG_128x64 || A.cfg == CFG_128x128) && !A.to_lowres &&
+                A.dsts.size() == 1 && A.dsts[0].first == po.in_tensor && (g.H % 2) == 0 && (g.W % 2) == 0 && A.level + 1 < e->nlevels;
+      for (auto& c : e->convs) if (c.in_tensor == po.in_tensor) ok = false;  // somebody convolves the un-pooled blob
+      if (!ok) continue;
+      A.pool = pi;
+      A.dsts[0] = {po.out_tensor, 0};
+      e->tensors[po.in_tensor].written = false;
+      e->steps.erase(e->steps.begin() + (long)si);
+      --si;
+    }
+  }
   {  // the input convolution without the im2col tensor: fp16 storage, 64 channels, one plain destination
     static const char* fd = getenv("RTP_FIRST_DIRECT");  // experiments: 0 = the pack + 1x1 route
     for (size_t si = 0; si + 1 < e->steps.size() && !(fd && fd[0] == '0'); ++si) {
@@ -849,6 +873,13 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   P.CoutP = A.CoutP;
   const ConvCfgInfo ci = conv_cfg_info(A.cfg);
   P.tiles_per_img = (int)(((long)g.H * g.Wp + ci.BM - 1) / ci.BM);
+  if (A.pool >= 0) {  // tiles of 2 image rows x BM/2 pixels, walked with an even pitch; the epilogue writes the next level's tensor
+    const Geom& go = e->geom[A.level + 1];
+    P.pool = 1;
+    P.pool_wq = (g.W + A.k_eff / 2 + 1) & ~1;
+    P.pool_Wp = go.Wp; P.pool_halo = go.halo; P.pool_img_pix = go.img_pix;
+    P.tiles_per_img = (int)(((long)(g.H / 2) * P.pool_wq + ci.BM / 2 - 1) / (ci.BM / 2));
+  }
   P.relu = A.relu ? 1 : 0;
   P.clkprobe = g_clkprobe;
   P.nimg = nimg;
@@ -1913,6 +1944,7 @@ int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int sh
   auto it = e->blob_tensor.find(name);
   if (it == e->blob_tensor.end()) return fail(e, RTP_EINVAL, "Unknown blob name %s", name);  // net.cpp blob_by_name warning
   const Tensor& t = e->tensors[it->second];
+  if (!t.written) return fail(e, RTP_EINVAL, "blob %s is not materialised: its convolution pools in the epilogue and writes only the pooled blob (create the engine with keep_blobs = 1 to tap it)", name);
   Geom g = e->geom[t.level];
   g.N = e->N;  // the taps run one frame (slot 0 of the batch)
   const size_t n = (size_t)g.N * t.C * g.H * g.W;
@@ -2173,8 +2205,9 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
       const ConvOp& A = e->convs[s.a];
       const ConvCfgInfo ci = conv_cfg_info(A.cfg);
       const Geom& g = e->geom[A.level];
-      const long tiles = ((long)g.H * g.Wp + ci.BM - 1) / ci.BM;
+      const long tiles = A.pool >= 0 ? ((long)(g.H / 2) * ((g.W + A.k_eff / 2 + 1) & ~1) + ci.BM / 2 - 1) / (ci.BM / 2) : ((long)g.H * g.Wp + ci.BM - 1) / ci.BM;
       o << "step conv " << A.name;
+      if (A.pool >= 0) o << " +pool";
       if (s.b >= 0) o << " + " << e->convs[s.b].name;
       o << " k " << A.k << " cin_p " << A.Cin_p << " cout " << A.cout << " coutp " << A.CoutP << " relu " << A.relu << " tile " << ci.BM << "x" << ci.BN
         << " rowb " << A.rowb << " passes " << A.passes() << (A.h8 ? "q" : "") << (!A.h8 && A.split_a ? "a" : "") << (!A.h8 && A.split_w ? "w" : "") << " impl " << (A.impl ? "ring" : "reg") << " wgs " << tiles * e->NI * (A.CoutP / ci.BN) * (s.b >= 0 ? 2 : 1) << " dsts " << A.dsts.size() << " lowres " << A.to_lowres << "\n";

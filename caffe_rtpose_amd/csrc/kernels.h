@@ -66,6 +66,11 @@ struct ConvParams {
   int spec;    // ring kernel: 1 = wave-specialised variant (4 DMA waves + 4 MFMA waves)
   int variant; // ring kernel experiments (env RTP_RING_VAR; see conv_ring.hip), 0 = production
   int ilv;     // ring kernel (wave-specialised, fp16): interleaved A-fragment rows, taps 1.. of a strip shift registers instead of re-reading LDS
+  // fused 2x2 max pooling (ring kernels, conv_ring.hip POOL): the M tile is 2 image rows x BM/2 pixels, the epilogue writes only the
+  // pooled tensor.  pool_wq = W + pad rounded up to even (pitch of the tile walk, so that every tile starts on an even x); pool_* =
+  // geometry of the pooled (next) level
+  int pool, pool_wq, pool_Wp, pool_halo;
+  long pool_img_pix;
   unsigned long long* clkprobe;  // diagnostics: {shader clock cycles, wall clock ticks} of workgroup 0 (spec ring kernels)
 };
 

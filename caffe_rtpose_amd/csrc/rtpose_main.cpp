@@ -63,7 +63,7 @@ struct Flags {
   int dry_people = 5;
   int producer_threads = 0;      // frames are generated / decoded ahead by this many threads (0 = hardware threads / 4, clamped to [2, 16])
   int json_writers = -1;         // JSON files are written by this many threads (0 = by the display/writer thread itself, like the reference;
-                                 // default: 1 thread per 2 workers — creating a file costs the one display thread ~0.5 ms, 1600 frames/s at most)
+                                 // default: 1 thread per worker — creating a file costs the one display thread ~0.5 ms, 1600 frames/s at most)
 };
 
 int parse_flags(int argc, char** argv, Flags& F) {
@@ -581,7 +581,7 @@ int main(int argc, char** argv) {
   if (F.precision != "mixed" && F.precision != "fp16" && F.precision != "f16x3" && F.precision != "fp32") { fprintf(stderr, "--precision must be mixed, fp16, f16x3 or fp32\n"); return 1; }
   if (F.frames_in_flight < 1 || F.frames_in_flight > 64) { fprintf(stderr, "--frames_in_flight must be in [1, 64]\n"); return 1; }
   if (F.batch_frames < 1 || F.batch_frames > 16) { fprintf(stderr, "--batch_frames must be in [1, 16]\n"); return 1; }
-  if (F.json_writers < 0) F.json_writers = (F.num_gpu + 1) / 2;
+  if (F.json_writers < 0) F.json_writers = F.num_gpu;
   if (F.dry_engine < 0 || F.json_writers > 64) { fprintf(stderr, "--dry_engine must be >= 0 and --json_writers in [0, 64]\n"); return 1; }
   if (F.dry_engine > 0 && !F.write_frames.empty()) { fprintf(stderr, "--dry_engine has no renderer: drop --write_frames\n"); return 1; }
   std::vector<int> devs;

@@ -88,6 +88,10 @@ typedef struct rtp_config {
                             * "<pattern>[:w|:a]": pattern = layer-name prefix, "*text" = name        *
                             * contains text, "@1x1" = every 1x1 layer, "@all"; ":w" splits only the  *
                             * weights, ":a" only the input activations, none = both.                  */
+  int keep_blobs;          /* 0 (default): blobs that only feed a fused consumer are not written (the     *
+                            * convolutions in front of the three pooling layers pool in their epilogue).   *
+                            * 1: every blob of the graph stays tappable by rtp_get_blob (= blob_by_name),   *
+                            * pooling runs as its own launch; same values either way.                       */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,

@@ -69,7 +69,7 @@ def test_conv_stack_fp16_path(model, W, H, N):
     bits, so the error is a random walk over 52 layers: bound 2e-2 of the blob's max magnitude,
     and the first layer (exact u8/256-0.5 inputs, one rounding of the output) at 2e-3."""
     import caffe_rtpose_amd as r
-    e = _engine(model=model, net_w=W, net_h=H, num_scales=N, precision=r.PREC_FP16, scale_gap=0.25, frames_in_flight=1)
+    e = _engine(model=model, net_w=W, net_h=H, num_scales=N, precision=r.PREC_FP16, scale_gap=0.25, frames_in_flight=1, keep_blobs=1)  # every blob tapped
     net = _oracle_net_from(e)
     x = _synth.random_frame(N, H, W, seed=8)
     got = e.forward_heatmaps(x)
@@ -80,6 +80,41 @@ def test_conv_stack_fp16_path(model, W, H, N):
     assert not bad, f"first diverging layers: {bad[:5]}"
     assert _rel_err(got, net.blob("concat_stage7")) < 2e-2
     e.close()
+
+
+@pytest.mark.parametrize("prec", ["fp16", "mixed", "f16x3"])
+@pytest.mark.parametrize("model,W,H,N,B", [(0, 656, 368, 1, 2), (1, 496, 368, 1, 1), (0, 320, 176, 2, 1), (0, 336, 208, 1, 3), (0, 64, 48, 1, 1)])
+def test_pooling_fused_into_the_convolution_epilogue_is_bit_identical(prec, model, W, H, N, B):
+    """Default plan: conv1_2 / conv2_2 / conv3_4 pool in their epilogue (2-row tiles, conv_ring.hip POOL) and write only the pooled
+    blob.  keep_blobs = 1 runs the same layers with the stand-alone pooling launches (pooling_layer.cpp:140-180 restated in
+    aux_kernels.hip, compared with the oracle by test_conv_stack_fp32_exact_path).  Same bytes: pooled blobs (their lo / fp8 parts
+    included: the export adds them), every later blob, the low-res maps."""
+    import caffe_rtpose_amd as r
+    P = {"fp16": r.PREC_FP16, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}[prec]
+    kw = dict(model=model, net_w=W, net_h=H, num_scales=N, precision=P, scale_gap=0.2, frames_in_flight=B, batch_frames=B)
+    ef = _engine(**kw)
+    ek = _engine(keep_blobs=1, **kw)
+    plan = r.plan_summary(ef.cfg)
+    nf = plan.count("+pool")   # small resolutions put some trunk layers on tiles without a pooled variant: those keep their pooling launch
+    assert nf >= (3 if W >= 640 else 2 if W >= 480 else 1 if W >= 320 else 0) and nf + plan.count("step pool") == 3 and r.plan_summary(ek.cfg).count("step pool") == 3
+    fused_away = [ln.split()[2] for ln in plan.splitlines() if "+pool" in ln]
+    x = _synth.random_frame(N, H, W, seed=21)
+    a, b = ef.forward_heatmaps(x), ek.forward_heatmaps(x)
+    assert np.array_equal(a, b)
+    for name in ("pool1_stage1", "pool2_stage1", "pool3_stage1", "conv2_1", "conv3_1", "conv4_4_CPM"):
+        assert np.array_equal(ef.get_blob(name), ek.get_blob(name)), name
+    for name in fused_away:
+        with pytest.raises(r.RtpError):
+            ef.get_blob(name)
+    assert ek.get_blob("conv1_2").shape == (N, 64, H, W)
+    if B > 1:   # full batches through submit / collect
+        for t in range(B):
+            ef.submit(x, tag=t)
+            ek.submit(x, tag=t)
+        ra, rb = [ef.collect() for _ in range(B)], [ek.collect() for _ in range(B)]
+        assert all(np.array_equal(p[2], q[2]) and p[1] == q[1] for p, q in zip(ra, rb))
+    ef.close()
+    ek.close()
 
 
 # ------------------------------------------------------------------------------------------

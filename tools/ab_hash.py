@@ -22,7 +22,7 @@ for prec_name, prec in (("fp16", r.PREC_FP16), ("mixed", r.PREC_MIXED)) + ((("f1
         d = e.forward_debug(x)
         h = hashlib.sha256(d["lowres"].tobytes()).hexdigest()[:16]
         extra = []
-        for name in ("conv2_2", "conv4_4_CPM", "Mconv5_stage4_L1"):
+        for name in ("pool2_stage1", "conv4_4_CPM", "Mconv5_stage4_L1"):
             try:
                 extra.append(hashlib.sha256(e.get_blob(name).tobytes()).hexdigest()[:8])
             except Exception as ex:  # noqa: BLE001

@@ -22,7 +22,7 @@ args = ap.parse_args()
 x = _synth.random_frame(args.n, args.h, args.w, seed=3)
 net = None
 for prec, pname in ((r.PREC_FP32, "fp32"), (r.PREC_FP16, "fp16")):
-    e = r.Engine(r.Config(model=args.model, net_w=args.w, net_h=args.h, num_scales=args.n, precision=prec, frames_in_flight=1, scale_gap=0.15))
+    e = r.Engine(r.Config(model=args.model, net_w=args.w, net_h=args.h, num_scales=args.n, precision=prec, frames_in_flight=1, scale_gap=0.15, keep_blobs=1))
     if net is None:
         net = orc.Net(args.model)
         for i in range(len(net.convs)):
