@@ -235,10 +235,8 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
   constexpr int CHUNKS = BN / 16, HALF = BM / 2, ITEMS = (HALF / 2) * CHUNKS;
   for (int item = threadIdx.x; item < ITEMS; item += 256) {
     const int k = item / CHUNKS, chunk = item % CHUNKS;
-    int x = x0 + 2 * k;
-    const int np_ = x / P.pool_wq;   // the tile walked past the pitch: these columns belong to a later row pair (pitch and x0 are even)
-    x -= np_ * P.pool_wq;
-    const int pr_ = pair + np_;
+    int x = x0 + 2 * k, pr_ = pair;
+    if (x >= P.pool_wq) { x -= P.pool_wq; ++pr_; }  // the tile walked past the pitch (at most once, pitch > BM/2): these columns open the next row pair
     const int c0 = n0 + chunk * 16;
     if (pr_ >= P.H / 2 || x >= P.W || c0 >= pr.Cout) continue;
     const long out_row = (long)img * P.pool_img_pix + (long)(pr_ + P.pool_halo) * P.pool_Wp + P.pool_halo;

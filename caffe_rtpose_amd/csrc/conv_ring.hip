@@ -286,10 +286,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       // x position in the (row pair, x) walk (real image columns; element (y, x) lives at padded column x + halo).  [0, W) are
       // pixels; [W, pitch) are zero columns — the right halo of this pair and the left halo of the next one — served by the
       // gap pixel that follows the row in memory; every further `pitch` positions = one row pair down.
+      // (the engine fuses only where the pitch exceeds a tile row + halo: at most ONE wrap per tile, no division on this path —
+      // a workgroup of conv1_2 lives ~8000 cycles, its prologue is not hidden behind anything)
       const int a = pool_x0 - PAD + (row - sel * PHALF);
-      const int np_ = a >= 0 ? a / P.pool_wq : 0;
-      const int ar = a - np_ * P.pool_wq;
-      src_pix = np_ * 2 * P.Wp + (ar < P.W ? ar : P.W) + P.halo + PAD + sel * P.Wp;
+      const bool wrap = a >= P.pool_wq;
+      const int ar = wrap ? a - P.pool_wq : a;
+      src_pix = (wrap ? 2 * P.Wp : 0) + (ar < P.W ? ar : P.W) + P.halo + PAD + sel * P.Wp;
     }
     a_voff[q] = (unsigned)(src_pix * (int)pix_bytes + ((cphys ^ ring_swz_a<CHB, TR::TM, ILV>(row)) * 16) - (q & 3) * 1024);
   }

@@ -493,16 +493,27 @@ int build_plan(rtp_engine* e) {
     e->steps.push_back({1, a, b});
     if (b >= 0) ++oi;
   }
-  for (auto& s : e->steps) {
+  for (size_t si_ = 0; si_ < e->steps.size(); ++si_) {
+    Step& s = e->steps[si_];
     if (s.type != 1) continue;
     ConvOp& A = e->convs[s.a];
     const Geom& g = e->geom[A.level];
+    // a pooling layer follows and reads only this blob: tiles the POOL kernel exists for save its launch (fusion pass below)
+    const bool pool_next = s.b < 0 && si_ + 1 < e->steps.size() && e->steps[si_ + 1].type == 2 && A.dsts.size() == 1 &&
+                           pools[e->steps[si_ + 1].a].in == A.name && (g.H % 2) == 0 && (g.W % 2) == 0 && g.W >= 128 && !e->cfg.keep_blobs;
     const int nprob = s.b >= 0 ? 2 : 1;
     const int maxcout = std::max(A.cout, s.b >= 0 ? e->convs[s.b].cout : 0);
     const long M = (long)g.H * g.Wp;
-    // Tile choice.  The layers are L2->LDS bandwidth bound, so among the tiles
-    // that give every CU a workgroup (>= 224 of 256) take the one that moves the fewest bytes:
-    // per workgroup one weight tile of BN rows and 1/k of a (BM+k-1)-row strip per tap.
+    // Tile choice by a time model of the ring kernel (cycles; the constants are measured):
+    //   one K step (tap x chunk) of a workgroup = max(MFMA time, L2->LDS time) + barrier:
+    //     MFMA:  BM*BN*channels_per_chunk / (4 consumer waves * 32*32*16) instructions per wave at ~43 cycles on real operands
+    //     DMA:   the weight tile (BN rows) + 1/k of the (BM+k-1)-pixel strip, at ~56 B/clk/CU
+    //   a workgroup = steps * that + ~4500 cycles of prologue / epilogue; a launch = workgroups / 256 CUs rounds, where a partial
+    //   round of fill f costs 0.5 + 0.5 f of a full one (fewer busy CUs clock higher and wait less for L2: 372 workgroups of the
+    //   dominant shape take 1.70x the time of 248, not 2x), + ~6000 cycles of dispatch per launch.  (Two co-resident workgroups of
+    //   the small-LDS 64x64 kernel share one matrix pipe: no credit for them.)
+    // Replaces round 2's "fewest bytes among the tiles with >= 224 workgroups", which left plans whose M does not fill the chip
+    // (MPI 46x62 maps at batch_frames 2: 192 workgroups of 128x64) on half-size tiles in two rounds.
     const bool ring_ok = !A.first && (A.k_eff == 3 || A.k_eff == 7);
     const int row_bytes_all = A.Cin_p * e->elem;
     std::vector<int> cands;
@@ -510,18 +521,35 @@ int build_plan(rtp_engine* e) {
     else if (maxcout <= 32 && ring_ok && row_bytes_all % 256 == 0) cands = {CFG_128x32, CFG_128x64, CFG_64x64};
     else if (maxcout <= 64) cands = {CFG_128x64, CFG_64x64};
     else if (ring_ok && row_bytes_all % 256 == 0) cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64, CFG_128x32};
+    else if (ring_ok) cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64};
     else cands = {CFG_128x128, CFG_64x128, CFG_64x64};
     int best = cands.back();
+    double best_t = 1e300, best_bytes = 1e300;
+    static const char* tm = getenv("RTP_TILE_RULE");  // experiments: "r2" = round 2's rule
+    const bool rule_r2 = tm && !strcmp(tm, "r2");
     long best_wg = -1;
-    double best_bytes = 1e300;
     bool chosen = false;
+    const int passes = (A.split_a || A.split_w) ? ((e->split_fp8 && e->mode == RTP_PREC_MIXED && A.split_a && A.split_w && ring_ok) ? 2 : 1 + (A.split_a ? 1 : 0) + (A.split_w ? 1 : 0)) : 1;
     for (int cf : cands) {
       const ConvCfgInfo ci = conv_cfg_info(cf);
       const long wg = ((M + ci.BM - 1) / ci.BM) * e->NI * (round_up(maxcout, ci.BN) / ci.BN) * nprob;
       const double bytes = (double)wg * (ci.BN + (double)(ci.BM + A.k_eff - 1) / A.k_eff);
-      if (wg >= 224) {
-        if (!chosen || bytes < best_bytes) { best = cf; best_bytes = bytes; chosen = true; }
-      } else if (!chosen && wg > best_wg) { best = cf; best_wg = wg; }
+      if (rule_r2) {
+        if (wg >= 224) { if (!chosen || bytes < best_bytes) { best = cf; best_bytes = bytes; chosen = true; } }
+        else if (!chosen && wg > best_wg) { best = cf; best_wg = wg; }
+        continue;
+      }
+      const int chb = (ring_ok && (cf == CFG_64x64 || cf == CFG_128x64 || cf == CFG_128x32) && row_bytes_all % 256 == 0) ? 256 : std::min(128, row_bytes_all);
+      const double chc = (double)chb / e->elem;                                     // channels per chunk
+      const double t_mfma = (double)ci.BM * ci.BN * chc / (4.0 * 32 * 32 * 16) * (e->prec ? 4 * 43.0 : 43.0);
+      const double t_dma = ((double)ci.BN * chb + (double)(ci.BM + A.k_eff - 1) * chb / A.k_eff) / 56.0;
+      const double steps = (double)A.k_eff * A.k_eff * (row_bytes_all / (double)chb) * passes;
+      const double t_wg = steps * (std::max(t_mfma, t_dma) + 60.0) + 4500.0;
+      const double full = std::floor((double)wg / 256.0), frac = (double)wg / 256.0 - full;
+      double t = (full + (frac > 0 ? 0.5 + 0.5 * frac : 0.0)) * t_wg + 6000.0;
+      if (pool_next && !(e->prec == 0 && A.k_eff == 3 && chb == 128 && (cf == CFG_128x64 || cf == CFG_128x128)))  // the stand-alone pooling launch: ~5 B per cycle and CU
+        t += 8000.0 + (double)e->NI * g.H * g.W * e->tensors[A.dsts[0].first].stride() * e->elem * 1.25 / (256.0 * 9.0);
+      if (t < best_t * 0.98 || (t < best_t * 1.02 && bytes < best_bytes)) { best = cf; best_t = std::min(t, best_t); best_bytes = bytes; }
     }
     {
       static const char* fc = getenv("RTP_FORCE_CFG");  // experiments only: force a tile for the k x k layers at 1/8 resolution
@@ -578,7 +606,7 @@ int build_plan(rtp_engine* e) {
       const PoolOp& po = e->pools[pi];
       const Geom& g = e->geom[A.level];
       bool ok = e->prec == 0 && A.impl == 1 && A.k_eff == 3 && A.rowb == 128 && (A.cfg == CFG_128x64 || A.cfg == CFG_128x128) && !A.to_lowres &&
-                A.dsts.size() == 1 && A.dsts[0].first == po.in_tensor && (g.H % 2) == 0 && (g.W % 2) == 0 && A.level + 1 < e->nlevels;
+                A.dsts.size() == 1 && A.dsts[0].first == po.in_tensor && (g.H % 2) == 0 && (g.W % 2) == 0 && g.W >= 128 /* one wrap per tile at most */ && A.level + 1 < e->nlevels;
       for (auto& c : e->convs) if (c.in_tensor == po.in_tensor) ok = false;  // somebody convolves the un-pooled blob
       if (!ok) continue;
       A.pool = pi;
@@ -895,7 +923,9 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
     static const char* rv = getenv("RTP_RING_VAR");
     P.variant = rv ? atoi(rv) : 0;
     static const char* il = getenv("RTP_RING_ILV");
-    P.ilv = (il && il[0] == '1') ? 1 : 0;
+    // interleaved A-fragment rows (conv_ring.hip ILV; bit-identical): default for the fp8-compensated launches, whose plain variant
+    // spills 6 registers (44.6 vs 45.3 us on the dominant shape); the plain fp16 launches are faster without.  "1" = all, "0" = none
+    P.ilv = il ? (il[0] == '1' || (il[0] == 'q' && A.h8)) : (A.h8 ? 1 : 0);
   }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));

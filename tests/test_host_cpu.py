@@ -91,7 +91,10 @@ def test_plan_coco_flops_and_pairing():
     assert sum(" + " in l for l in convs) == 28 and all(l.count(" + ") == 2 for l in pw2)
     assert any("conv4_4_CPM" in l and "dsts 6" in l for l in convs)  # own tensor + 5 concat slices
     assert [l for l in pw2 if "Mconv7_stage6" in l][0].endswith("lowres 1")
-    assert sum(l.startswith("step pool") for l in lines) == 3
+    # the three pooling layers run inside the epilogues of conv1_2 / conv2_2 / conv3_4 (conv_ring.hip POOL); keep_blobs = 1 keeps their launches
+    assert sum(l.startswith("step pool") for l in lines) == 0 and sum("+pool" in l for l in convs) == 3
+    kept = _plan_lines(keep_blobs=1)
+    assert sum(l.startswith("step pool") for l in kept) == 3 and not any("+pool" in l for l in kept)
     # 3 scales: same graph, 3x the work
     l3 = _plan_lines(num_scales=3, scale_gap=0.15)
     assert float([l for l in l3 if l.startswith("conv_gflop")][0].split()[1]) == pytest.approx(3 * 484.634, abs=3e-3)
