@@ -360,7 +360,10 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
   float* out = (float*)lds_raw;                 // [strip_rows + 2][W]
   float* T = out + (p.strip_rows + 2) * W;      // [NMSF_TROWS][W]
   XTab* xt = (XTab*)(T + NMSF_TROWS * W);       // [W]
+  float* colmax = T + (NMSF_TROWS - 1) * W;     // [r.w <= W]: max |low-res value| per low-res column over the rows this strip touches; lives in the LAST
+                                                // row of T, which is only written when a strip needs all NMSF_TROWS rows — then col_skip is off (below)
   __shared__ int wave_cnt[4];
+  __shared__ float strip_max, strip_min, wave_min[4];
   const int strip = blockIdx.x, part = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = strip * p.strip_rows;
@@ -368,6 +371,67 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
   const int ya = max(y0 - 1, 0), yb = min(y1, H - 1);  // rows held in LDS: ya..yb
   const int nrow = yb - ya + 1;
   const long plane = (long)r.h * r.w;
+  // ---- what cannot hold a maximum is not evaluated (exactly) -------------------------------------------------------------
+  // A resized value is sum_n cubic(cubic(...)) / num of a 4x4 low-res neighbourhood per scale.  |cubic(v0..v3, d)| <=
+  // S * max|v_i| with S = sum_i |w_i(d)| <= 1.375 for d in [-0.5, 1] (1.25 inside, 1.375 at the border where axis_nb's d is
+  // negative, imresize_layer.cu:123-128), so |value| <= 1.375^2 * max|neighbourhood| = 1.8906 * max; NMS_BOUND adds 3 % for the
+  // float / double roundings of cubic_interp.  nms_register_kernel (nms_layer.cu:15-46) flags only pixels with v > threshold:
+  // where NMS_BOUND * max|low-res neighbourhood| <= threshold there is no flag, and such a pixel is also no obstacle to a
+  // neighbour's flag (that neighbour has v > threshold >= it).  Strip level (any number of scales): nothing in the low-res rows
+  // of this strip is large enough -> count 0, done.  Column level (one scale): columns whose 4 low-res columns are too small
+  // get the placeholder `threshold` instead of their value.  On real heat maps most of a part's plane is background.
+  constexpr float NMS_BOUND = 1.95f;
+  float smax = 0.f, smin = __builtin_inff();  // largest / smallest column maximum
+  for (int n = 0; n < r.num; ++n) {
+    const ScaleGeo g = scale_geo(r, n);
+    const float* sp = r.src + ((long)n * r.C + part) * plane;
+    int nb[4];
+    (void)axis_nb(ya, g.offset_y, g.fy, g.oh, g.padh, nb);
+    const int rlo = nb[0];
+    (void)axis_nb(yb, g.offset_y, g.fy, g.oh, g.padh, nb);
+    const int rhi = nb[3];
+    float m = 0.f;
+    for (int c = tid; c < g.ow; c += 256) {
+      float cm = 0.f;
+      for (int rr = rlo; rr <= rhi; ++rr) {
+        const float a = fabsf(sp[rr * g.rw + g.padw + c]);
+        if (!(a <= cm)) cm = (a == a) ? a : __builtin_inff();
+      }
+      if (r.num == 1) colmax[c] = cm;
+      m = cm > m ? cm : m;
+      smin = cm < smin ? cm : smin;
+    }
+    smax = m > smax ? m : smax;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(smax, o), u = __shfl_xor(smin, o);
+    smax = t > smax ? t : smax;
+    smin = u < smin ? u : smin;
+  }
+  if (lane == 0) { ((float*)wave_cnt)[wave] = smax; wave_min[wave] = smin; }
+  __syncthreads();
+  if (tid == 0) {
+    const float* wm = (const float*)wave_cnt;
+    float m = wm[0], mn = wave_min[0];
+    for (int w = 1; w < 4; ++w) { m = wm[w] > m ? wm[w] : m; mn = wave_min[w] < mn ? wave_min[w] : mn; }
+    strip_max = m;
+    strip_min = mn;
+  }
+  __syncthreads();
+  if (!(NMS_BOUND * strip_max > p.threshold)) {
+    if (tid == 0) p.strip_count[part * p.nstrips + strip] = 0;
+    return;
+  }
+  // column level only where it can skip something (noise maps: every column is above the bound; the tests below would be overhead)
+  bool col_skip = r.num == 1 && !(NMS_BOUND * strip_min > p.threshold);
+  if (col_skip) {  // colmax shares T's last row: only while the strip's low-res rows leave that row free (always with net/8 maps and 8- or 16-row strips)
+    const ScaleGeo g0 = scale_geo(r, 0);
+    int nb[4];
+    (void)axis_nb(ya, g0.offset_y, g0.fy, g0.oh, g0.padh, nb);
+    const int lo = nb[0];
+    (void)axis_nb(yb, g0.offset_y, g0.fy, g0.oh, g0.padh, nb);
+    if (nb[3] - lo + 1 >= NMSF_TROWS) col_skip = false;
+  }
   for (int n = 0; n < r.num; ++n) {
     const ScaleGeo g = scale_geo(r, n);
     const float* sp = r.src + ((long)n * r.C + part) * plane;
@@ -382,6 +446,16 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
         const float x_on = (x - g.offset_x) * g.fx;
         int xn1 = (int)((double)x_on + 1e-5);
         xn1 = (xn1 < 0) ? 0 : xn1;
+        if (col_skip) {  // one scale: is any of this column's 4 low-res columns large enough?  (xn1 = -1 marks "no")
+          const int x0 = (xn1 - 1 < 0) ? xn1 : (xn1 - 1);
+          const int x2 = (xn1 + 1 >= g.ow) ? (g.ow - 1) : (xn1 + 1);
+          const int x3 = (x2 + 1 >= g.ow) ? (g.ow - 1) : (x2 + 1);
+          float m = colmax[x0];
+          m = colmax[xn1] > m ? colmax[xn1] : m;
+          m = colmax[x2] > m ? colmax[x2] : m;
+          m = colmax[x3] > m ? colmax[x3] : m;
+          if (!(NMS_BOUND * m > p.threshold)) xn1 = -1;
+        }
         xt[x].xn1 = xn1;
         xt[x].dx = x_on - xn1;
       }
@@ -391,6 +465,7 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
         float* trow = T + rr * W;
         for (int x = tid; x < W; x += 256) {
           const XTab e = xt[x];
+          if (e.xn1 < 0) continue;   // column below the bound (col_skip)
           const int x0 = (e.xn1 - 1 < 0) ? e.xn1 : (e.xn1 - 1);
           const int x2 = (e.xn1 + 1 >= g.ow) ? (g.ow - 1) : (e.xn1 + 1);
           const int x3 = (x2 + 1 >= g.ow) ? (g.ow - 1) : (x2 + 1);
@@ -404,6 +479,7 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
         const float *t0 = T + (yn[0] - rlo) * W, *t1 = T + (yn[1] - rlo) * W, *t2 = T + (yn[2] - rlo) * W, *t3 = T + (yn[3] - rlo) * W;
         float* orow = out + yy * W;
         for (int x = tid; x < W; x += 256) {
+          if (col_skip && xt[x].xn1 < 0) { orow[x] = p.threshold; continue; }  // (one scale: this is the final value)
           const float d = cubic_interp(t0[x], t1[x], t2[x], t3[x], dy);
           orow[x] = (n == 0 ? 0.f : orow[x]) + d;
         }
