@@ -1073,6 +1073,7 @@ NmsParams nms_params(rtp_engine* e, Ctx& cx, int sj) {
   np.src = sl.resized; np.peaks = sl.peaks; np.strip_count = sl.strip_count; np.strip_list = sl.strip_list;
   np.src_planes = e->heat_channels; np.H = e->cfg.net_h; np.W = e->cfg.net_w; np.num_parts = e->num_parts;
   np.max_peaks = e->max_peaks; np.nstrips = e->nstrips; np.strip_rows = e->strip_rows; np.threshold = e->nms_threshold;
+  np.probe = nullptr;
   return np;
 }
 int run_nms(rtp_engine* e, Ctx& cx, int sj = 0) {
@@ -1865,6 +1866,21 @@ int rtp_post_from_lowres(rtp_engine* e, const float* lowres, float* peaks, float
   const size_t pbytes = (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float);
   HIPCHK(e, hipMemcpy(cx.lowres, lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyHostToDevice));
   if (peaks) HIPCHK(e, hipMemcpy(sl.peaks, peaks, pbytes, hipMemcpyHostToDevice));  // stale slots stay, like the reference's blob
+  if (getenv("RTP_NMS_PROBE")) {  // diagnostics: phase stamps of the middle strip workgroup of part 0
+    unsigned long long* d = nullptr;
+    HIPCHK(e, hipMalloc((void**)&d, 32 * 8));
+    HIPCHK(e, hipMemset(d, 0, 32 * 8));
+    NmsParams np = nms_params(e, cx, 0);
+    np.probe = d;
+    HIPCHK(e, launch_nms_fused(np, resize_params(e, cx, 0), sl.stream));
+    HIPCHK(e, hipStreamSynchronize(sl.stream));
+    unsigned long long h[32];
+    HIPCHK(e, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    fprintf(stderr, "nms strip probe (us):");
+    for (unsigned i = 2; i <= h[0] && i < 32; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[i - 1]) / 100.0);
+    fprintf(stderr, "  total %.2f\n", h[0] ? (double)(h[h[0]] - h[1]) / 100.0 : 0.0);
+  }
   HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
   if ((rc = run_post_fused(e, cx, 0, sl.ev[2]))) return rc;
   HIPCHK(e, hipEventRecord(sl.ev[3], sl.stream));

@@ -200,6 +200,7 @@ struct NmsParams {
   int* strip_list;   // [num_parts][nstrips][max_peaks]  flat pixel index of the first max_peaks maxima of the strip
   int src_planes, H, W, num_parts, max_peaks, nstrips, strip_rows;
   float threshold;
+  unsigned long long* probe;  // diagnostics (RTP_NMS_PROBE): wall-clock stamps of the phases of one strip workgroup, [0] = count
 };
 hipError_t launch_nms(const NmsParams& p, hipStream_t stream);
 // Production path: the same peaks WITHOUT materialising the resized map — each strip workgroup

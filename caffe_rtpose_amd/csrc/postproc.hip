@@ -42,12 +42,26 @@ namespace rtp {
 // ---------------------------------------------------------------------------------------
 // ImResize
 // ---------------------------------------------------------------------------------------
+// imresize_layer.cu:14-17 with C++'s usual arithmetic conversions spelled out, in two halves: the three sub-expressions that do
+// not depend on the fraction (8 consecutive outputs along an axis share them), and the evaluation at a fraction.  Same
+// operations in the same order as the one-piece expression (no contraction in this file): cubic_interp IS this pair.
+struct CubicCoef { float a; double b; float c; float v1; };
+__device__ __forceinline__ CubicCoef cubic_coef(float v0, float v1, float v2, float v3) {
+  CubicCoef k;
+  k.a = (-0.5f * v0 + 1.5f * v1 - 1.5f * v2 + 0.5f * v3);
+  k.b = ((double)(v0 - 2.5f * v1) + 2.0 * (double)v2 - 0.5 * (double)v3);
+  k.c = (-0.5f * v0 + 0.5f * v2);
+  k.v1 = v1;
+  return k;
+}
+__device__ __forceinline__ float cubic_eval(const CubicCoef& k, float dx) {
+  const float t1 = k.a * dx * dx * dx;
+  const double t2 = k.b * (double)dx * (double)dx;
+  const float t3 = k.c * dx;
+  return (float)((((double)t1 + t2) + (double)t3) + (double)k.v1);
+}
 __device__ __forceinline__ float cubic_interp(float v0, float v1, float v2, float v3, float dx) {
-  // imresize_layer.cu:14-17 with C++'s usual arithmetic conversions spelled out
-  const float t1 = (-0.5f * v0 + 1.5f * v1 - 1.5f * v2 + 0.5f * v3) * dx * dx * dx;
-  const double t2 = ((double)(v0 - 2.5f * v1) + 2.0 * (double)v2 - 0.5 * (double)v3) * (double)dx * (double)dx;
-  const float t3 = (-0.5f * v0 + 0.5f * v2) * dx;
-  return (float)((((double)t1 + t2) + (double)t3) + (double)v1);
+  return cubic_eval(cubic_coef(v0, v1, v2, v3), dx);
 }
 
 // Geometry of scale n (imresize_layer.cu:99-131)
@@ -353,9 +367,14 @@ __global__ __launch_bounds__(256) void nms_write_kernel(NmsParams p) {
 // item that is constant along a row or a column: loops run row by row (no integer division), the x-axis neighbour / fraction
 // of every column is tabulated once per scale (xt), the y-axis ones are uniform per row, the first scale assigns 0 + d instead
 // of a zero pass, and the final division is skipped for one scale (x / 1 == x).  Same operations on the same values.
+struct YTab { int o0, o1, o2, o3; float dy; };  // one output row: offsets of its four row interpolations in T, fraction
 struct XTab { int xn1; float dx; };  // axis_nb's clamped integer position (before padding) and fraction of one output column
+#define NMS_STAMP() do { if (probe_me) { __syncthreads(); if (threadIdx.x == 0 && stamp_i < 30) p.probe[++stamp_i] = wall_clock64(); } } while (0)
 __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, ResizeParams r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const bool probe_me = p.probe && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;  // uniform
+  int stamp_i = 0;
+  NMS_STAMP();
   const int W = p.W, H = p.H;
   float* out = (float*)lds_raw;                 // [strip_rows + 2][W]
   float* T = out + (p.strip_rows + 2) * W;      // [NMSF_TROWS][W]
@@ -364,6 +383,7 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
                                                 // row of T, which is only written when a strip needs all NMSF_TROWS rows — then col_skip is off (below)
   __shared__ int wave_cnt[4];
   __shared__ float strip_max, strip_min, wave_min[4];
+  __shared__ YTab ytab[24];
   const int strip = blockIdx.x, part = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = strip * p.strip_rows;
@@ -418,6 +438,7 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
     strip_min = mn;
   }
   __syncthreads();
+  NMS_STAMP();  // 2: bound pre-pass
   if (!(NMS_BOUND * strip_max > p.threshold)) {
     if (tid == 0) p.strip_count[part * p.nstrips + strip] = 0;
     return;
@@ -460,31 +481,77 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
         xt[x].dx = x_on - xn1;
       }
       __syncthreads();
+      NMS_STAMP();  // 3: column table
+      // Row interpolations.  The ~8 output columns of one low-res cell share cubic_coef (19 of cubic_interp's 33 operations and
+      // its 4 loads): where T has room behind its nt rows, the coefficients are tabulated per (low-res row, cell) first.
+      float4* ctab = (float4*)(T + nt * W);   // [nt][ow] {a, c, b as two words}
+      const bool use_ctab = (long)nt * g.ow * 4 <= (long)(NMSF_TROWS - nt) * W && (W & 3) == 0;
+      if (use_ctab) {
+        for (int it = tid; it < nt * g.ow; it += 256) {
+          const int rr = it / g.ow, c = it - rr * g.ow;
+          const float* row = sp + (rlo + rr) * g.rw + g.padw;
+          const int x0 = (c - 1 < 0) ? c : (c - 1);
+          const int x2 = (c + 1 >= g.ow) ? (g.ow - 1) : (c + 1);
+          const int x3 = (x2 + 1 >= g.ow) ? (g.ow - 1) : (x2 + 1);
+          const CubicCoef k = cubic_coef(row[x0], row[c], row[x2], row[x3]);
+          float4 q;
+          q.x = k.a; q.y = k.c;
+          __builtin_memcpy(&q.z, &k.b, 8);
+          ctab[it] = q;
+        }
+        __syncthreads();
+      }
+      NMS_STAMP();  // 4: coefficient table
       for (int rr = 0; rr < nt; ++rr) {
         const float* row = sp + (rlo + rr) * g.rw + g.padw;
         float* trow = T + rr * W;
         for (int x = tid; x < W; x += 256) {
           const XTab e = xt[x];
           if (e.xn1 < 0) continue;   // column below the bound (col_skip)
-          const int x0 = (e.xn1 - 1 < 0) ? e.xn1 : (e.xn1 - 1);
-          const int x2 = (e.xn1 + 1 >= g.ow) ? (g.ow - 1) : (e.xn1 + 1);
-          const int x3 = (x2 + 1 >= g.ow) ? (g.ow - 1) : (x2 + 1);
-          trow[x] = cubic_interp(row[x0], row[e.xn1], row[x2], row[x3], e.dx);
+          if (use_ctab) {
+            const float4 q = ctab[rr * g.ow + e.xn1];
+            CubicCoef k;
+            k.a = q.x; k.c = q.y; k.v1 = row[e.xn1];
+            __builtin_memcpy(&k.b, &q.z, 8);
+            trow[x] = cubic_eval(k, e.dx);
+          } else {
+            const int x0 = (e.xn1 - 1 < 0) ? e.xn1 : (e.xn1 - 1);
+            const int x2 = (e.xn1 + 1 >= g.ow) ? (g.ow - 1) : (e.xn1 + 1);
+            const int x3 = (x2 + 1 >= g.ow) ? (g.ow - 1) : (x2 + 1);
+            trow[x] = cubic_interp(row[x0], row[e.xn1], row[x2], row[x3], e.dx);
+          }
         }
       }
       __syncthreads();
-      for (int yy = 0; yy < nrow; ++yy) {
+      NMS_STAMP();  // 5: row interpolations
+      // Column interpolation, one thread per output column: the rows of one low-res cell share cubic_coef of the four row
+      // interpolations above / below (the y neighbourhood and fraction of every row are tabulated first: uniform per row)
+      if (tid < nrow) {
         int yn[4];
-        const float dy = axis_nb(ya + yy, g.offset_y, g.fy, g.oh, g.padh, yn);  // uniform over the row
-        const float *t0 = T + (yn[0] - rlo) * W, *t1 = T + (yn[1] - rlo) * W, *t2 = T + (yn[2] - rlo) * W, *t3 = T + (yn[3] - rlo) * W;
-        float* orow = out + yy * W;
-        for (int x = tid; x < W; x += 256) {
-          if (col_skip && xt[x].xn1 < 0) { orow[x] = p.threshold; continue; }  // (one scale: this is the final value)
-          const float d = cubic_interp(t0[x], t1[x], t2[x], t3[x], dy);
-          orow[x] = (n == 0 ? 0.f : orow[x]) + d;
+        ytab[tid].dy = axis_nb(ya + tid, g.offset_y, g.fy, g.oh, g.padh, yn);
+        ytab[tid].o0 = (yn[0] - rlo) * W; ytab[tid].o1 = (yn[1] - rlo) * W; ytab[tid].o2 = (yn[2] - rlo) * W; ytab[tid].o3 = (yn[3] - rlo) * W;
+      }
+      __syncthreads();
+      for (int x = tid; x < W; x += 256) {
+        if (col_skip && xt[x].xn1 < 0) {  // (one scale: this is the final value)
+          for (int yy = 0; yy < nrow; ++yy) out[yy * W + x] = p.threshold;
+          continue;
+        }
+        int prev = -1;
+        CubicCoef k;
+        for (int yy = 0; yy < nrow; ++yy) {
+          const YTab yt = ytab[yy];
+          if (yt.o1 != prev) {
+            prev = yt.o1;
+            k = cubic_coef(T[yt.o0 + x], T[yt.o1 + x], T[yt.o2 + x], T[yt.o3 + x]);
+          }
+          const float d = cubic_eval(k, yt.dy);
+          float* o = out + yy * W + x;
+          *o = (n == 0 ? 0.f : *o) + d;
         }
       }
       __syncthreads();
+      NMS_STAMP();  // 6: column interpolations
     } else {  // a strip spanning more low-res rows than the table holds (not with net/8 maps): per pixel
       for (int i = tid; i < nrow * W; i += 256) {
         const int yy = i / W, x = i - yy * W;
@@ -519,30 +586,44 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
   const int g0 = wave * gper, g1 = min(g0 + gper, ngroups);
   int mine = 0;
   {
+    // nms_register_kernel, nms_layer.cu:15-46.  All nine values of a pixel are read unconditionally and three groups are in
+    // flight per iteration: the loop was a chain of dependent LDS round trips (6.2 of a workgroup's 21 us, RTP_NMS_PROBE).
     int q = g0 * 64 + lane;            // this lane's pixel of group g, as (x, y) without a division per group
     int py = y0 + q / W, px = q % W;
     const float thr = p.threshold;
-    for (int g = g0; g < g1; ++g) {
-      int f = 0;
-      if (q < npix && px > 0 && px < W - 1 && py > 0 && py < H - 1) {  // nms_register_kernel, nms_layer.cu:15-46
-        const float* c = s + py * W + px;
-        const float v = c[0];
-        if (v > thr) {
-          const float top = c[-W], bottom = c[W], left = c[-1], right = c[1];
-          const float tl = c[-W - 1], tr = c[-W + 1], bl = c[W - 1], br = c[W + 1];
-          if (v > top && v > bottom && v > left && v > right && v > tl && v > bl && v > br && v > tr) f = 1;
-        }
-      }
-      const unsigned long long bal = __ballot(f);
-      if (lane == 0) bals[g] = bal;
-      mine += __popcll(bal);
+    auto flag_at = [&](int qq, int x, int y) __attribute__((always_inline)) {
+      const bool in = qq < npix && x > 0 && x < W - 1 && y > 0 && y < H - 1;
+      const float* c = s + (in ? y * W + x : ya * W + 1 + W);   // any interior address when out of range (nrow >= 2 there or the flag is dropped)
+      const float v = c[0], top = c[-W], bottom = c[W], left = c[-1], right = c[1];
+      const float tl = c[-W - 1], tr = c[-W + 1], bl = c[W - 1], br = c[W + 1];
+      return in && v > thr && v > top && v > bottom && v > left && v > right && v > tl && v > bl && v > br && v > tr;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
       q += 64;
       px += 64;
       while (px >= W) { px -= W; ++py; }
+    };
+    int g = g0;
+    for (; g + 2 < g1; g += 3) {
+      const int qa = q, xa_ = px, ya_ = py; advance();
+      const int qb = q, xb_ = px, yb_ = py; advance();
+      const int qc = q, xc_ = px, yc_ = py; advance();
+      const bool fa = flag_at(qa, xa_, ya_), fb = flag_at(qb, xb_, yb_), fc = flag_at(qc, xc_, yc_);
+      const unsigned long long ba = __ballot(fa), bb = __ballot(fb), bc = __ballot(fc);
+      if (lane == 0) { bals[g] = ba; bals[g + 1] = bb; bals[g + 2] = bc; }
+      mine += __popcll(ba) + __popcll(bb) + __popcll(bc);
+    }
+    for (; g < g1; ++g) {
+      const bool f = flag_at(q, px, py);
+      const unsigned long long bal = __ballot(f);
+      if (lane == 0) bals[g] = bal;
+      mine += __popcll(bal);
+      advance();
     }
   }
   if (lane == 0) wave_cnt[wave] = mine;
   __syncthreads();
+  NMS_STAMP();  // 7: flags + ballots
   int ord0 = 0;
   for (int w = 0; w < wave; ++w) ord0 += wave_cnt[w];
   for (int g = g0; g < g1 && ord0 < p.max_peaks; ++g) {
@@ -552,6 +633,8 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
     ord0 += __popcll(bal);
   }
   if (tid == 0) p.strip_count[part * p.nstrips + strip] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  NMS_STAMP();  // 8: list
+  if (probe_me && tid == 0) p.probe[0] = stamp_i;
 }
 
 // Write kernel: the 49 window values of every kept peak are evaluated on demand by all threads,

@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python $R/bench.py --precision $P > $O/bench_${P}_n1.json 2> $O/bench_${P}_n1.err
 tail -c 400 $O/bench_${P}_n1.json
-rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --precision $P --no_cpu_baseline --no_sub_results > $O/bench_${P}_n1_under_rocprof.json 2> /tmp/kt.err
+rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --precision $P --no_cpu_baseline --no_sub_results --no_parity > $O/bench_${P}_n1_under_rocprof.json 2> /tmp/kt.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_${P}_n1_kernel_stats.csv
 python $R/tools/timeline.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) > $O/bench_${P}_n1_timeline.txt 2>&1
 [ "${2:-}" = nopmc ] && exit 0   # bench line + kernel stats only
