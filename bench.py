@@ -251,9 +251,11 @@ def main():
                          "north-star tolerance (+-1e-3 on maps normalised to 1, tests/test_precision.py); fp16 = single-pass everywhere (2x outside it); "
                          "f16x3 = every layer as three fp16 passes; fp32 = exact-f32 MFMA")
     ap.add_argument("--split_layers", default=None, help="override the split set of --precision mixed (rtp_config.split_layers syntax)")
-    ap.add_argument("--in_flight", type=int, default=None, help="frames in flight per GPU (default 8; 10 for MPI = two batches of 5)")
+    ap.add_argument("--in_flight", type=int, default=None, help="frames in flight per GPU (default 7 = three launched batches of 2 + one staged frame; "
+                    "3 at several scales; 10 for MPI = two batches of 5): measured optima, profiles/r03_in_flight.txt")
     ap.add_argument("--batch_frames", type=int, default=None, help="frames whose conv stacks share one launch sequence (1 = the reference's one frame per Forward); "
-                    "default 2 for COCO 656x368 (248 workgroups per 1/8-resolution launch), 5 for MPI 496x368 (240 workgroups of 128x128 tiles)")
+                    "default 2 for COCO 656x368 at 1 scale (248 workgroups per 1/8-resolution launch), 1 at several scales, 5 for MPI 496x368 "
+                    "(240 workgroups of 128x128 tiles)")
 
     ap.add_argument("--model", default="coco", choices=["coco", "mpi"], help="coco = BASELINE configs[1..3] (656x368); mpi = configs[4] (15 parts, 496x368)")
     ap.add_argument("--exec", dest="exec_mode", default="graph", choices=["graph", "eager"])
@@ -263,9 +265,9 @@ def main():
     ap.add_argument("--dry_dispatch", action="store_true", help="self-test of the multi-rank plumbing without a GPU (gloo, no engine): tests/test_bench_spawn.py")
     args = ap.parse_args()
     if args.batch_frames is None:
-        args.batch_frames = 5 if args.model == "mpi" else 2
+        args.batch_frames = 5 if args.model == "mpi" else (2 if args.num_scales == 1 else 1)
     if args.in_flight is None:
-        args.in_flight = 10 if args.model == "mpi" else 8
+        args.in_flight = 10 if args.model == "mpi" else (7 if args.num_scales == 1 else 3) if args.batch_frames in (1, 2) else 2 * args.batch_frames
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_launcher(args))
@@ -492,12 +494,12 @@ def sub_results(args, r, eng, make_engine, device_frames, measure, W, H, gflop, 
     # (3) 3 scales, gap 0.15 (BASELINE configs[2], the north-star target configuration)
     if args.num_scales == 1 and args.model == "coco":
         try:
-            e3 = make_engine(args.precision, 3, 0.15, args.batch_frames, args.in_flight)
+            e3 = make_engine(args.precision, 3, 0.15, 1, 3)   # one frame (3 images) per launch sequence, 3 frames in flight: the measured optimum
             f3 = device_frames(3)
-            m = measure(e3, lambda i, tag: e3.submit_device(f3[i % len(f3)].data_ptr(), tag=tag), in_flight=args.in_flight, **short)
+            m = measure(e3, lambda i, tag: e3.submit_device(f3[i % len(f3)].data_ptr(), tag=tag), in_flight=3, **short)
             peak = 157.3e12 if args.precision == "fp32" else 2.5e15
             res["scales3_gap0.15"] = {"value": m["fps"], "unit": "frames/s", "steps_timed": m["steps_timed"], "p50_ms": float(np.percentile(m["lat"], 50) * 1e3),
-                                      "conv_stack_frac_of_peak": m["fps"] * gflop * 3e9 / peak}
+                                      "conv_stack_frac_of_peak": m["fps"] * gflop * 3e9 / peak, "batch_frames": 1, "frames_in_flight": 3}
             if not args.no_parity:
                 try:
                     res["scales3_gap0.15"]["parity"] = parity_report(e3, oracle_frames(e3, 3, args.model, 0, seed0=7)[1], args.model, 3, 0.15)
