@@ -165,7 +165,8 @@ struct Global {
   std::vector<int> per_worker;  // frames each worker submitted (dynamic pull from the one shared queue)
   std::atomic<int> workers_ready{0};  // workers start pulling once EVERY engine is up (engine creation takes seconds, short inputs milliseconds)
   std::atomic<bool> producer_done{false};
-  double first_commit = 0, last_written = 0;  // steady-state window: first frame committed .. last frame written
+  double first_commit = 0;                     // steady-state window: first frame committed .. last file written
+  std::atomic<double> last_written{0};         // (by the display thread, or by whichever JSON writer finished last)
   BlockingQueue<Frame> json_queue;             // --json_writers K
   std::atomic<bool> json_done{false};
   int num_parts = 18;
@@ -487,6 +488,9 @@ void json_writer() {
       continue;
     }
     write_json_file(fr, buf);
+    const double now = wall();
+    double prev = G.last_written.load();
+    while (prev < now && !G.last_written.compare_exchange_weak(prev, now)) {}
   }
 }
 
@@ -518,7 +522,11 @@ void writer(std::atomic<bool>* reorder_done) {
       } else write_json_file(fr, buf);
     }
     G.finished++;
-    G.last_written = wall();
+    {
+      const double now = wall();
+      double prev = G.last_written.load();
+      while (prev < now && !G.last_written.compare_exchange_weak(prev, now)) {}
+    }
     counter++;
     if (counter % 30 == 0) {  // rtpose.cpp:1421-1441
       const double now = wall();
@@ -626,7 +634,7 @@ int main(int argc, char** argv) {
   for (int s : status) rc |= s;
   const double dt = wall() - t0;
   for (int g = 0; g < F.num_gpu; ++g) fprintf(stderr, "worker %d (GPU %d) processed %d frames\n", g, devs[g], G.per_worker[g]);
-  const double steady = (G.finished.load() > 1 && G.last_written > G.first_commit) ? G.finished.load() / (G.last_written - G.first_commit) : 0.0;
+  const double steady = (G.finished.load() > 1 && G.last_written.load() > G.first_commit) ? G.finished.load() / (G.last_written.load() - G.first_commit) : 0.0;
   fprintf(stderr, "rtcpm %s. Total time: %.3f seconds. frames produced %d, written %d, dropped %d (%.1f FPS incl. init, %.1f FPS first frame committed -> last frame written)\n",
           rc ? "FAILED" : "successfully finished", dt, G.produced.load(), G.finished.load(), G.dropped.load(), G.finished.load() / dt, steady);
   return rc;

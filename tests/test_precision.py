@@ -1,6 +1,6 @@
 """Precision of the conv stack in NORTH-STAR units (BASELINE.json: keypoints within +-1 px / +-1e-3 confidence of
 the reference's fp32 CPU path), for the exact plans bench.py times: COCO 656x368 at batch_frames 1 and 2, 3 scales
-(gap 0.15), MPI 496x368 — each against the CPU oracle's fp32 conv stack (base_conv_layer.cpp:257-280 restated,
+(gap 0.15) at batch_frames 1 (the 3-scale sub-result) and 2, MPI 496x368 at batch_frames 1, 2 and 5 (bench.py --model mpi) — each against the CPU oracle's fp32 conv stack (base_conv_layer.cpp:257-280 restated,
 pinned on the reference's KATs) on the same synthetic weights and frame.
 
 Units: the synthetic network's final maps have max |v| ~ 5; real confidence maps live in [0, 1].  The branch-final
@@ -26,6 +26,7 @@ CONFIGS = {  # name -> (model, W, H, num_scales, scale_gap, batch_frames)
     "coco_3s_b2": (0, 656, 368, 3, 0.15, 2),   # the plan bench.py's 3-scale sub-result times (6 images per launch: other tiles than 3)
     "mpi_1s_b1": (1, 496, 368, 1, 0.3, 1),
     "mpi_1s_b2": (1, 496, 368, 1, 0.3, 2),
+    "mpi_1s_b5": (1, 496, 368, 1, 0.3, 5),     # bench.py --model mpi: 240 workgroups of 128x128 tiles per 1/8-resolution launch
 }
 TOL = {"fp32": 1e-4, "f16x3": 1e-4, "mixed": 1e-3, "fp16": 3e-3}
 _ref_cache = {}
