@@ -295,10 +295,16 @@ def main():
         def fake(n, base):
             time.sleep(0.001 * n)
         steps = scaled_steps(args.steps, 1000.0, min(args.min_seconds, 0.2), dist)
-        dt = timed_region(fake, steps, args.warmup, dist)
+        dt, dt_local = timed_region(fake, steps, args.warmup, dist, return_local=True)
+        per_rank = [steps / dt_local]
+        if dist is not None:   # the same gather the GPU path does (there on the device)
+            t = torch.zeros(world, dtype=torch.float64)
+            t[rank] = steps / dt_local
+            dist.all_reduce(t)
+            per_rank = [float(v) for v in t.tolist()]
         if rank == 0:
             print(json.dumps({"metric": "dispatch self-test (no GPU work)", "value": aggregate_fps(steps, world, dt), "unit": "frames/s", "n_gpus": world,
-                              "steps": args.steps, "steps_timed": steps, "warmup": args.warmup, "data": "none"}))
+                              "steps": args.steps, "steps_timed": steps, "warmup": args.warmup, "data": "none", "per_rank_frames_per_s": per_rank}))
         if dist is not None:
             dist.destroy_process_group()
         return

@@ -25,6 +25,7 @@ def test_bare_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 2
     assert out["steps_timed"] >= 20              # --steps is a minimum: scaled to --min_seconds, same on every rank
     assert out["value"] > 0
+    assert len(out["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in out["per_rank_frames_per_s"])   # a straggler would show here
 
 
 def test_single_rank_needs_no_launcher():

