@@ -83,7 +83,7 @@ def test_conv_stack_fp16_path(model, W, H, N):
 
 
 @pytest.mark.parametrize("prec", ["fp16", "mixed", "f16x3"])
-@pytest.mark.parametrize("model,W,H,N,B", [(0, 656, 368, 1, 2), (1, 496, 368, 1, 1), (0, 320, 176, 2, 1), (0, 336, 208, 1, 3), (0, 64, 48, 1, 1)])
+@pytest.mark.parametrize("model,W,H,N,B", [(0, 656, 368, 1, 2), (1, 496, 368, 1, 1), (0, 320, 176, 2, 1), (0, 336, 208, 1, 3), (0, 720, 400, 2, 2), (0, 64, 48, 1, 1)])
 def test_pooling_fused_into_the_convolution_epilogue_is_bit_identical(prec, model, W, H, N, B):
     """Default plan: conv1_2 / conv2_2 / conv3_4 pool in their epilogue (2-row tiles, conv_ring.hip POOL) and write only the pooled
     blob.  keep_blobs = 1 runs the same layers with the stand-alone pooling launches (pooling_layer.cpp:140-180 restated in
