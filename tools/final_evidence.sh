@@ -1,5 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$PWD}   # round-end evidence on the GPU box: GPU tests, precision output, smoke, bench lines (3 scales, MPI), steps, CLI, then tools/collect_profiles.sh
 O=gpurun_out/final; mkdir -p $O
 timeout 1800 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 900 python -m pytest tests/test_precision.py -q -s -m gpu > $O/precision_tests.txt 2>&1; tail -2 $O/precision_tests.txt
