@@ -100,6 +100,38 @@ def test_plan_coco_flops_and_pairing():
     assert float([l for l in l3 if l.startswith("conv_gflop")][0].split()[1]) == pytest.approx(3 * 484.634, abs=3e-3)
 
 
+def _tiles(lines, needle):
+    out = set()
+    for l in lines:
+        if l.startswith("step conv") and needle in l:
+            w = l.split()
+            out.add((w[w.index("tile") + 1], int(w[w.index("rowb") + 1]), int(w[w.index("wgs") + 1])))
+    return out
+
+
+def test_tile_model_choices_of_the_benched_plans():
+    """engine.cpp build_plan scores tiles by a time model (MFMA vs L2->LDS time per K step, partial rounds, dispatch, credit for tiles
+    that pool in the epilogue).  The choices below are the ones measured on the GPU (profiles/r03_tile_model.txt, r03_steps.txt)."""
+    dom = " k 7 cin_p 128 cout 128 "
+    entry = " k 7 cin_p 192 cout 128 "
+    # COCO 656x368, batches of 2 (bench.py default): 248 workgroups of 128x64 tiles, 256-byte chunks; stage-entry layers 128x64 with 128-byte chunks
+    b2 = _plan_lines(batch_frames=2)
+    assert _tiles(b2, dom) == {("128x64", 256, 248)} and _tiles(b2, entry) == {("128x64", 128, 248)}
+    # MPI 496x368 (46x65 padded pixels = 24 M tiles): batches of 5 fill the chip with 128x128 tiles (bench.py --model mpi) ...
+    m5 = _plan_lines(model=1, net_w=496, net_h=368, batch_frames=5)
+    assert _tiles(m5, dom) == {("128x128", 128, 240)}
+    # ... and at batches of 2 ONE under-filled round of 128x64 tiles beats two rounds of 128x32 (round 2's rule: 384 workgroups; 1089 -> 1240 frames/s)
+    m2 = _plan_lines(model=1, net_w=496, net_h=368, batch_frames=2)
+    assert _tiles(m2, dom) == {("128x64", 256, 192)}
+    # 3 scales, one frame per launch sequence (bench.py's 3-scale configuration): 186 workgroups of 128x128 tiles, two conv stacks share the chip
+    s3 = _plan_lines(num_scales=3, scale_gap=0.15, batch_frames=1)
+    assert _tiles(s3, dom) == {("128x128", 128, 186)}
+    # the three layers in front of a pooling layer keep 128-pixel tiles of 128-byte chunks (the POOL kernel) in all of them
+    for pl in (b2, m5, s3):
+        pooled = [l for l in pl if "+pool" in l]
+        assert pooled and all(" rowb 128 " in l and (" tile 128x64 " in l or " tile 128x128 " in l) for l in pooled)
+
+
 def test_plan_mpi_and_errors():
     import caffe_rtpose_amd as r
     lines = _plan_lines(model=1, net_w=496, net_h=368)
