@@ -925,7 +925,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
     static const char* il = getenv("RTP_RING_ILV");
     // interleaved A-fragment rows (conv_ring.hip ILV; bit-identical): default for the fp8-compensated launches, whose plain variant
     // spills 6 registers (44.6 vs 45.3 us on the dominant shape); the plain fp16 launches are faster without.  "1" = all, "0" = none
-    P.ilv = il ? (il[0] == '1' || (il[0] == 'q' && A.h8)) : (A.h8 ? 1 : 0);
+    P.ilv = il ? (il[0] == '1' || (il[0] == 'q' && A.h8) || (il[0] == '7' && A.h8 && A.k_eff == 7)) : (A.h8 ? 1 : 0);
   }
   if (A.impl == 1) HIPCHK(e, launch_conv_ring(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
   else HIPCHK(e, launch_conv(e->prec, A.cfg, A.k_eff, A.rowb, P, s.b >= 0 ? 2 : 1, nimg, cx.stream));
