@@ -551,6 +551,11 @@ int build_plan(rtp_engine* e) {
         t += 8000.0 + (double)e->NI * g.H * g.W * e->tensors[A.dsts[0].first].stride() * e->elem * 1.25 / (256.0 * 9.0);
       if (t < best_t * 0.98 || (t < best_t * 1.02 && bytes < best_bytes)) { best = cf; best_t = std::min(t, best_t); best_bytes = bytes; }
     }
+    if (const char* ov = getenv("RTP_TILE_OVERRIDE")) {  // experiments: "conv2_1=3,conv3_1=3" forces tile ids (kernels.h ConvCfg) per layer
+      const std::string key = A.name + "=";
+      const char* hit = strstr(ov, key.c_str());
+      if (hit && (hit == ov || hit[-1] == ',')) best = atoi(hit + key.size());
+    }
     {
       static const char* fc = getenv("RTP_FORCE_CFG");  // experiments only: force a tile for the k x k layers at 1/8 resolution
       if (fc && ring_ok && A.level == 3 && maxcout > 64) best = atoi(fc);
