@@ -1127,11 +1127,21 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
   for (int j = 0; j < nframes; ++j) {
     Slot& sl = cx.slot[j];
     if (sl.stream != cx.stream) HIPCHK(e, hipStreamWaitEvent(sl.stream, cx.ev[1], 0));
-    static const char* diag = getenv("RTP_DIAG_SKIP_POST");  // diagnosis only: 1 = no connect, 2 = no post-processing at all
-    const int skip = diag ? atoi(diag) : 0;
+    static const char* diag = getenv("RTP_DIAG_SKIP_POST");  // diagnosis only: 1 = no connect, 2 = no post-processing at all (both through the
+    const int skip = diag ? atoi(diag) : 0;                  // materialised map); 3..6 = production kernels: 3 nms only, 4 + pairs, 5 + match, 6 all
     static const char* unf = getenv("RTP_POST_UNFUSED");  // experiments: production path through the materialised map
     HIPCHK(e, hipEventRecord(sl.ev[0], sl.stream));
-    if (materialize || skip || (unf && unf[0] == '1')) {
+    if (skip >= 3) {
+      const ResizeParams rp = resize_params(e, cx, j);
+      HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
+      HIPCHK(e, launch_nms_fused(nms_params(e, cx, j), rp, sl.stream));
+      HIPCHK(e, hipEventRecord(sl.ev[2], sl.stream));
+      if (skip >= 4) {
+        ConnectParams cp = connect_params(e, cx, j);
+        cp.diag_stages = skip - 3;   // 1 pairs, 2 + match, 3 + assemble
+        HIPCHK(e, launch_connect_fused(cp, rp, sl.stream));
+      }
+    } else if (materialize || skip || (unf && unf[0] == '1')) {
       if (skip < 2 && (rc = run_resize(e, cx, j))) return rc;
       HIPCHK(e, hipEventRecord(sl.ev[1], sl.stream));
       if (skip < 2 && (rc = run_nms(e, cx, j))) return rc;

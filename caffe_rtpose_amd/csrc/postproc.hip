@@ -915,13 +915,12 @@ __device__ __forceinline__ float key_score(unsigned long long key) {
   return __uint_as_float(u);
 }
 
-__global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+// one limb of connect_match_kernel (k was blockIdx.x); every thread of the workgroup calls it
+__device__ __forceinline__ void connect_match_limb(const ConnectParams& p, const int k, unsigned char* lds_raw) {
   unsigned long long* keys = (unsigned long long*)lds_raw;  // [pow2 >= survivors]
   __shared__ int running;
   __shared__ int flags;  // 1: NaN score seen   2: greedy scan met an ambiguous tie
   __shared__ int s_cnt;
-  const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cap = p.max_peaks * p.max_peaks;
   const bool coco = p.model == 0;
@@ -1091,6 +1090,18 @@ __global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
   if (tid == 0) {
     p.cand_count[k] = nc | (flags ? (1 << 30) : 0);  // bit 30: the exact path ran (diagnostics only)
     p.conn_count[k] = s_cnt;
+  }
+}
+
+// One workgroup per limb by default.  RTP_MATCH_WGS = n lets n workgroups take the limbs in turn: an experiment on WHY the
+// post-processing costs the pipeline 3x its CU time (profiles/r03_pool_and_postproc.txt section 5).  Hypothesis: 19 workgroups of ~95 us
+// hold 19 CUs while convolution launches need 248 at once.  Result: fewer workgroups are SLOWER (19: 1053 frames/s, 8: 1028, 4: 1017,
+// 2: 973) — what the chain costs is its latency (a frame holds its pipeline slot until its joints are on the host), not the CUs.
+__global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  for (int k = blockIdx.x; k < p.num_limbs; k += gridDim.x) {
+    connect_match_limb(p, k, lds_raw);
+    __syncthreads();  // the next limb re-initialises the shared state
   }
 }
 
@@ -1283,10 +1294,13 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
     hipLaunchKernelGGL(connect_pairs_kernel<true>, dim3((cap + PAIRS_WG - 1) / PAIRS_WG, p.num_limbs), dim3(PAIRS_WG), stage ? lds0 : 0, stream, p, *r, stage);
   } else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + PAIRS_WG - 1) / PAIRS_WG, p.num_limbs), dim3(PAIRS_WG), 0, stream, p, ResizeParams{}, 0);
   e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(connect_match_kernel, dim3(p.num_limbs), dim3(256), lds1, stream, p);
+  if (e != hipSuccess || p.diag_stages == 1) return e;
+  static const char* mw = getenv("RTP_MATCH_WGS");  // experiments: workgroups of the match kernel (default: one per limb)
+  int match_wgs = mw ? atoi(mw) : p.num_limbs;
+  if (match_wgs < 1 || match_wgs > p.num_limbs) match_wgs = p.num_limbs;
+  hipLaunchKernelGGL(connect_match_kernel, dim3(match_wgs), dim3(256), lds1, stream, p);
   e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || p.diag_stages == 2) return e;
   hipLaunchKernelGGL(connect_assemble_kernel, dim3(1), dim3(256), lds2, stream, pa);
   return hipGetLastError();
 }
