@@ -97,7 +97,7 @@ struct PoolOp { int in_tensor, out_tensor, C; };
 // One frame's post-processing state (a batch context carries batch_frames of them)
 struct Slot {
   hipStream_t stream = nullptr;  // resize -> nms -> connect -> D2H of this frame (slot 0 shares the context's stream)
-  bool own_stream = false;
+  bool own_stream = false, preset_stream = false;
   float* resized = nullptr;
   float* peaks = nullptr;
   int* strip_count = nullptr;
@@ -127,7 +127,7 @@ struct Slot {
 
 // One batch in flight: the conv stack runs once over filled*num_scales images
 struct Ctx {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, spare_stream = nullptr;
   unsigned char* arena = nullptr;
   float* input = nullptr;     // device NCHW fp32, batch_frames * num_scales images
   float* host_in = nullptr;   // pinned staging
@@ -1251,7 +1251,8 @@ hipError_t make_stream(hipStream_t* s, const char* env_name) {
 }
 
 int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
-  if (share_stream) sl.stream = cx.stream;
+  if (sl.preset_stream) {}  // RTP_STREAM_PLAN: alloc_ctx chose it
+  else if (share_stream) sl.stream = cx.stream;
   else { HIPCHK(e, make_stream(&sl.stream, "RTP_POST_PRIO")); sl.own_stream = true; }
   const size_t res_floats = (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w;
   HIPCHK(e, hipMalloc((void**)&sl.resized, res_floats * sizeof(float)));
@@ -1278,6 +1279,21 @@ int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
 }
 
 int alloc_ctx(rtp_engine* e, Ctx& cx) {
+  // RTP_STREAM_PLAN=1 (experiment): the runtime hands its 4 hardware queues to streams round-robin in creation order.  Create four
+  // streams per context so that conv stacks alternate between queues 0 / 1 and BOTH post-processing chains of a batch sit on queues
+  // 2 / 3: no post chain ever stands in front of another context's conv stack.  (Default: conv stream, then the extra slots' streams:
+  // with batches of 2 the conv stacks share queues 0 / 2 with frame 0's chains, frame 1's chains use queues 1 / 3.)
+  static const char* plan = getenv("RTP_STREAM_PLAN");
+  const bool planned = plan && plan[0] == '1' && e->B == 2;
+  std::vector<hipStream_t> planned_streams;
+  if (planned) {
+    const int ci = (int)(&cx - &e->ctx[0]);
+    hipStream_t q[4];
+    for (int i = 0; i < 4; ++i) HIPCHK(e, hipStreamCreateWithFlags(&q[i], hipStreamNonBlocking));
+    cx.stream = q[ci & 1];
+    cx.spare_stream = q[(ci & 1) ^ 1];
+    planned_streams = {q[2], q[3]};
+  } else
   HIPCHK(e, make_stream(&cx.stream, "RTP_CONV_PRIO"));
   HIPCHK(e, hipMalloc((void**)&cx.arena, e->arena_bytes));
   HIPCHK(e, hipMemset(cx.arena, 0, e->arena_bytes));
@@ -1293,6 +1309,11 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   for (int j = 0; j < e->B; ++j) {
     int rc;
     static const char* own0 = getenv("RTP_POST_OWN0");  // experiments: 1 = frame 0's post-processing chain also gets its own stream
+    if (planned) {
+      cx.slot[j].stream = planned_streams[j];
+      cx.slot[j].own_stream = true;
+      cx.slot[j].preset_stream = true;
+    }
     if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0 && !(own0 && own0[0] == '1')))) return rc;
   }
   return RTP_OK;
@@ -1318,6 +1339,7 @@ void free_ctx(Ctx& cx) {
   for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
   for (int i = 0; i < 2; ++i) if (cx.gev[i]) (void)hipEventDestroy(cx.gev[i]);
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
+  if (cx.spare_stream) (void)hipStreamDestroy(cx.spare_stream);
   cx = Ctx();
 }
 
