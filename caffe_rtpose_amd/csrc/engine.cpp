@@ -1316,6 +1316,10 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
     }
     if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0 && !(own0 && own0[0] == '1')))) return rc;
   }
+  {
+    static const char* sh1 = getenv("RTP_POST_SHARE1");  // experiments: 1 = frame 0's chain runs on frame 1's stream (behind nothing of the conv queues)
+    if (sh1 && sh1[0] == '1' && e->B >= 2 && !planned && cx.slot[0].stream == cx.stream) cx.slot[0].stream = cx.slot[1].stream;
+  }
   return RTP_OK;
 }
 
