@@ -19,6 +19,7 @@ import _synth
 
 pytestmark = pytest.mark.gpu
 
+SEEDS = {"coco_1s_b2_wseed5": 5, "coco_3s_wseed9": 9}   # other synthetic weight sets (rtp_config.synthetic_seed; default 1) and other frames
 CONFIGS = {  # name -> (model, W, H, num_scales, scale_gap, batch_frames)
     "coco_1s_b1": (0, 656, 368, 1, 0.3, 1),
     "coco_1s_b2": (0, 656, 368, 1, 0.3, 2),
@@ -27,6 +28,8 @@ CONFIGS = {  # name -> (model, W, H, num_scales, scale_gap, batch_frames)
     "mpi_1s_b1": (1, 496, 368, 1, 0.3, 1),
     "mpi_1s_b2": (1, 496, 368, 1, 0.3, 2),
     "mpi_1s_b5": (1, 496, 368, 1, 0.3, 5),     # bench.py --model mpi: 240 workgroups of 128x128 tiles per 1/8-resolution launch
+    "coco_1s_b2_wseed5": (0, 656, 368, 1, 0.3, 2),   # the split set was chosen on weight seed 1: the tolerance must hold on weights it never saw
+    "coco_3s_wseed9": (0, 656, 368, 3, 0.15, 1),
 }
 TOL = {"fp32": 1e-4, "f16x3": 1e-4, "mixed": 1e-3, "fp16": 3e-3}
 _ref_cache = {}
@@ -36,14 +39,14 @@ def _prec(r, name):
     return {"fp16": r.PREC_FP16, "fp32": r.PREC_FP32, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}[name]
 
 
-def _reference(model, W, H, N, e):
-    """fp32 reference maps of the UNSCALED synthetic net for the test frame (cached per geometry)."""
-    key = (model, W, H, N)
+def _reference(model, W, H, N, e, wseed=1):
+    """fp32 reference maps of the UNSCALED synthetic net for the test frame (cached per geometry and weight seed)."""
+    key = (model, W, H, N, wseed)
     if key not in _ref_cache:
         net = orc.Net(model)
         for i in range(len(net.convs)):
             net.set_weights(i, *e.get_conv_weights(i))
-        x = _synth.random_frame(N, H, W, seed=3)
+        x = _synth.random_frame(N, H, W, seed=3 if wseed == 1 else 100 + wseed)
         _ref_cache[key] = (x, net.forward(x))
     return _ref_cache[key]
 
@@ -94,12 +97,15 @@ def _explain(lone, res_here, res_other, thr, norm, who):
               f" other side {out[1][1] / norm:+.2e}, {out[1][2] / norm:+.2e}")
 
 
-@pytest.mark.parametrize("mode,cfg", [(m, c) for m in ("mixed", "fp16") for c in CONFIGS] + [("f16x3", "coco_1s_b1"), ("fp32", "coco_1s_b2")])
+@pytest.mark.parametrize("mode,cfg", [(m, c) for m in ("mixed", "fp16") for c in CONFIGS if m == "mixed" or c not in SEEDS] +
+                         [("f16x3", "coco_1s_b1"), ("fp32", "coco_1s_b2")])
 def test_final_maps_and_keypoints_within_tolerance(mode, cfg):
     import caffe_rtpose_amd as r
     model, W, H, N, gap, B = CONFIGS[cfg]
-    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, scale_gap=gap, precision=_prec(r, mode), frames_in_flight=B, batch_frames=B))
-    x, ref = _reference(model, W, H, N, e)
+    wseed = SEEDS.get(cfg, 1)
+    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, scale_gap=gap, precision=_prec(r, mode), frames_in_flight=B, batch_frames=B,
+                          synthetic_seed=wseed))
+    x, ref = _reference(model, W, H, N, e, wseed)
     # bring the maps into the range real confidences live in: exact power-of-two scaling of the linear branch-final layers
     s = float(2.0 ** -np.ceil(np.log2(np.abs(ref).max())))
     last = [i for i, (nm, *_rest) in enumerate(e.conv_layers()) if nm.startswith(("Mconv7_stage6_L", ))]
