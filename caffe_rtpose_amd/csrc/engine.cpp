@@ -551,6 +551,24 @@ int build_plan(rtp_engine* e) {
         t += 8000.0 + (double)e->NI * g.H * g.W * e->tensors[A.dsts[0].first].stride() * e->elem * 1.25 / (256.0 * 9.0);
       if (t < best_t * 0.98 || (t < best_t * 1.02 && bytes < best_bytes)) { best = cf; best_t = std::min(t, best_t); best_bytes = bytes; }
     }
+    // Half-chip launches.  The runtime's hardware queues run two conv stacks at a time, so two launches of <= 128
+    // workgroups share the chip: each workgroup moves half the weight bytes per MFMA and one stack's launch gaps are covered by the
+    // other's kernel.  Measured in the pipeline, same box (profiles/r03_tile_model.txt): 128x128 tiles (124 workgroups at batch_frames 2)
+    // for every k x k layer at 1/8 resolution +2.7 % frames/s, for all of them except the dominant shape +1.5..3 %.  A launch alone then
+    // fills half the chip, which is what a per-launch roofline reports (0.16 instead of 0.23 for the dominant 7x7 128->128 pair).
+    // RTP_HALF_CHIP: 1 (default) = where a 128x128 tile gives 100..128 workgroups and the model's choice 129..256, except the dominant
+    // shape (whose per-launch efficiency is the figure this path is judged on); 2 = the dominant shape too; 0 = the model alone.
+    if (!rule_r2 && ring_ok) {
+      static const char* hc = getenv("RTP_HALF_CHIP");
+      const int mode = hc ? atoi(hc) : 1;
+      const ConvCfgInfo cb = conv_cfg_info(best);
+      const long wg_best = ((M + cb.BM - 1) / cb.BM) * e->NI * (round_up(maxcout, cb.BN) / cb.BN) * nprob;
+      const long wg_128 = ((M + 127) / 128) * e->NI * (round_up(maxcout, 128) / 128) * nprob;
+      const bool has128 = std::find(cands.begin(), cands.end(), (int)CFG_128x128) != cands.end();
+      const bool dominant = A.k_eff == 7 && A.cin == 128;
+      if (mode > 0 && has128 && best != CFG_128x128 && wg_best > 128 && wg_best <= 256 && wg_128 >= 100 && wg_128 <= 128 && (mode >= 2 || !dominant))
+        best = CFG_128x128;
+    }
     if (const char* ov = getenv("RTP_TILE_OVERRIDE")) {  // experiments: "conv2_1=3,conv3_1=3" forces tile ids (kernels.h ConvCfg) per layer
       const std::string key = A.name + "=";
       const char* hit = strstr(ov, key.c_str());
@@ -558,7 +576,8 @@ int build_plan(rtp_engine* e) {
     }
     {
       static const char* fc = getenv("RTP_FORCE_CFG");  // experiments only: force a tile for the k x k layers at 1/8 resolution
-      if (fc && ring_ok && A.level == 3 && maxcout > 64) best = atoi(fc);
+      static const char* kd = getenv("RTP_FORCE_CFG_KEEP_DOM");  // 1: ... except the dominant shape (7x7, 128 input channels)
+      if (fc && ring_ok && A.level == 3 && maxcout > 64 && !(kd && kd[0] == '1' && A.k_eff == 7 && A.cin == 128)) best = atoi(fc);
     }
     const ConvCfgInfo ci = conv_cfg_info(best);
     const char* force = getenv("RTP_CONV_IMPL");
