@@ -224,6 +224,36 @@ def pmc_traffic(precision, batch_frames, num_scales, model, suffix=""):
     return best
 
 
+def roofline_block(dom_ms, dom_n, dom_flops, byp, solo_ms, peak, tr=None, tr2=None):
+    """The `roofline` object of the bench line from the event timings of the dominant launches (total ms, launches, FLOPs per launch,
+    {passes: (ms, launches)}), the same kernel timed alone (solo_ms per launch) and the PMC traffic records.  A per-launch figure that
+    is implausible against the solo timing is REPLACED by it, with the reason in `how`; `frac` never leaves (0, 1]."""
+    ms = dom_ms / max(dom_n, 1)
+    how = "HIP event pair around every launch of this kernel shape, on the launch's stream, over 40 batches processed one at a time (whole frames, no other frame's kernels on the chip)"
+    byp = dict(byp or {})
+    max_passes = max(byp) if byp else 1
+    if not (dom_n > 0 and solo_ms > 0 and 0.5 * solo_ms <= ms <= 10.0 * max_passes * solo_ms):   # implausible against the same kernel timed alone: say so, never print a fantasy
+        how = f"FALLBACK to the solo timing: the per-launch events gave {ms:.6g} ms over {dom_n} launches, outside [0.5x, {10 * max_passes}x] of the solo launch ({solo_ms:.4f} ms)"
+        ms, byp, dom_ms, dom_n = solo_ms, {}, solo_ms, 1
+    achieved = dom_flops / (ms * 1e-3) if ms > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "conv_ring_kernel 7x7 128->128 (L1+L2 branch pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
+            "unit": "TFLOP/s", "frac": min(max(achieved / peak, 0.0), 1.0), "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
+            "ms_per_launch": ms, "launches_timed": dom_n, "flops_per_launch": dom_flops, "how": how}
+    if tr2:  # the fp8-compensated launches of the same shape read the q blocks and the fp8 weight chunks as well
+        roof["traffic_2q"] = tr2["bytes"]
+        roof["traffic_2q_source"] = tr2["source"]
+    if byp:
+        exec_flops = sum(p * n for p, (_, n) in byp.items()) * dom_flops
+        roof["by_mfma_passes"] = {str(p): {"launches": n, "ms_per_launch": t / n, "algorithmic_tflops": dom_flops / (t / n * 1e-3) / 1e12,
+                                           "executed_mfma_tflops": p * dom_flops / (t / n * 1e-3) / 1e12} for p, (t, n) in byp.items()}
+        roof["executed"] = {"mfma_tflops": exec_flops / (dom_ms * 1e-3) / 1e12, "frac_of_peak": exec_flops / (dom_ms * 1e-3) / peak,
+                            "note": "matrix-pipe work actually issued, in fp16-pass equivalents (error-compensated launches: 2 or 3 passes per algorithmic flop)"}
+    if solo_ms > 0:
+        roof["solo"] = {"ms_per_launch": solo_ms, "achieved": dom_flops / (solo_ms * 1e-3) / 1e12, "frac": dom_flops / (solo_ms * 1e-3) / peak,
+                        "what": "the plain fp16 instantiation, 200 launches back to back between two events"}
+    return roof
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` with no launcher: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -405,29 +435,9 @@ def main():
         # `executed` (pass-time equivalents: an fp8 chunk takes the time of the fp16 chunk it corrects).
         peak = 157.3e12 if args.precision == "fp32" else 2.5e15
         solo_ms, _ = eng.bench_dominant_conv(iters=200)   # the plain instantiation back to back, alone on the chip (HIP events around 200 launches)
-        ms = dom_ms / max(dom_n, 1)
-        how = "HIP event pair around every launch of this kernel shape, on the launch's stream, over 40 batches processed one at a time (whole frames, no other frame's kernels on the chip)"
-        max_passes = max(byp) if byp else 1
-        if not (dom_n > 0 and 0.5 * solo_ms <= ms <= 10.0 * max_passes * solo_ms):   # implausible against the same kernel timed alone: say so, never print a fantasy
-            how = f"FALLBACK to the solo timing: the per-launch events gave {ms:.6g} ms over {dom_n} launches, outside [0.5x, {10 * max_passes}x] of the solo launch ({solo_ms:.4f} ms)"
-            ms, byp = solo_ms, {}
-        achieved = dom_flops / (ms * 1e-3)
-        tr = pmc_traffic(args.precision, args.batch_frames, args.num_scales, args.model)
-        tr2 = pmc_traffic(args.precision, args.batch_frames, args.num_scales, args.model, "_2q")
-        roof = {"bound": "mfma", "kernel": "conv_ring_kernel 7x7 128->128 (L1+L2 branch pair)", "achieved": achieved / 1e12, "peak": peak / 1e12,
-                "unit": "TFLOP/s", "frac": min(max(achieved / peak, 0.0), 1.0), "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                "ms_per_launch": ms, "launches_timed": dom_n, "flops_per_launch": dom_flops, "how": how}
-        if tr2:  # the fp8-compensated launches of the same shape read the q blocks and the fp8 weight chunks as well
-            roof["traffic_2q"] = tr2["bytes"]
-            roof["traffic_2q_source"] = tr2["source"]
-        if byp:
-            exec_flops = sum(p * n for p, (_, n) in byp.items()) * dom_flops
-            roof["by_mfma_passes"] = {str(p): {"launches": n, "ms_per_launch": t / n, "algorithmic_tflops": dom_flops / (t / n * 1e-3) / 1e12,
-                                               "executed_mfma_tflops": p * dom_flops / (t / n * 1e-3) / 1e12} for p, (t, n) in byp.items()}
-            roof["executed"] = {"mfma_tflops": exec_flops / (dom_ms * 1e-3) / 1e12, "frac_of_peak": exec_flops / (dom_ms * 1e-3) / peak,
-                                "note": "matrix-pipe work actually issued, in fp16-pass equivalents (error-compensated launches: 2 or 3 passes per algorithmic flop)"}
-        roof["solo"] = {"ms_per_launch": solo_ms, "achieved": dom_flops / (solo_ms * 1e-3) / 1e12, "frac": dom_flops / (solo_ms * 1e-3) / peak,
-                        "what": "the plain fp16 instantiation, 200 launches back to back between two events"}
+        roof = roofline_block(dom_ms, dom_n, dom_flops, byp, solo_ms, peak,
+                              pmc_traffic(args.precision, args.batch_frames, args.num_scales, args.model),
+                              pmc_traffic(args.precision, args.batch_frames, args.num_scales, args.model, "_2q"))
         fps = m["fps"]
         whole = {"achieved": fps / world * gflop * 1e9 * args.num_scales / 1e12, "unit": "TFLOP/s",
                  "frac": fps / world * gflop * 1e9 * args.num_scales / peak}

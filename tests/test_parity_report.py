@@ -53,3 +53,29 @@ def test_empty_sides():
     assert r["people_ref"] == 0 and r["joints_structural"] == 36
     m = _parity.merge([_parity.people_parity(a, a), _parity.people_parity(a, z)])
     assert m["frames"] == 2 and m["people_matched"] == 2 and m["people_engine"] == 4
+
+
+def _bench():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rtp_bench_cpu", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_roofline_block_never_prints_a_fantasy():
+    """bench.py's `roofline` object: a per-launch timing that is implausible against the same kernel timed alone (round 2's driver run:
+    1.02e9 ms per launch from cross-XCD clock stamps -> frac 9.5e-12) is replaced by the solo timing and says so; frac stays in (0, 1]."""
+    b = _bench()
+    flops, peak, solo = 24.226e9, 2.5e15, 0.0255
+    good = b.roofline_block(0.0307 * 320 + 0.0513 * 480, 800, flops, {1: (0.0307 * 320, 320), 2: (0.0513 * 480, 480)}, solo, peak)
+    assert 0.2 < good["frac"] < 0.25 and "FALLBACK" not in good["how"] and set(good["by_mfma_passes"]) == {"1", "2"}
+    assert abs(good["by_mfma_passes"]["2"]["ms_per_launch"] - 0.0513) < 1e-9 and 0.3 < good["executed"]["frac_of_peak"] < 0.5
+    bad = b.roofline_block(1.02e9 * 800, 800, flops, {1: (1.02e9 * 320, 320), 2: (1.02e9 * 480, 480)}, solo, peak)   # the round-2 driver record
+    assert "FALLBACK" in bad["how"] and bad["ms_per_launch"] == solo and 0.3 < bad["frac"] < 0.45 and "by_mfma_passes" not in bad
+    none = b.roofline_block(0.0, 0, flops, {}, solo, peak)                                                            # nothing harvested
+    assert "FALLBACK" in none["how"] and 0 < none["frac"] <= 1
+    fast = b.roofline_block(1e-6 * 10, 10, flops, {1: (1e-5, 10)}, solo, peak)                                       # absurdly fast
+    assert "FALLBACK" in fast["how"] and 0 < fast["frac"] <= 1
