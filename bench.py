@@ -10,13 +10,19 @@ Multi-GPU: one process per GPU, frames sharded (full replicas, no data-path coll
 re-executes itself under torch.distributed.run with N ranks (RCCL); under a launcher it reads
 RANK/LOCAL_RANK/WORLD_SIZE.
 
-The timed region is never shorter than --min_seconds (default 2 s): `--steps K` is a MINIMUM, the number of
-frames actually timed is reported as `steps_timed` and `ms_per_step` refers to it.  (A 20-frame region with
-8 frames in flight is mostly pipeline fill/drain and measures the host, not the GPU.)
+The timed region is never shorter than --min_seconds (default 2 s) and runs un-instrumented: `--steps K` is a MINIMUM, the region is
+repeated with more frames until it is long enough, and the line reports the frames actually timed as `steps` (= `steps_timed`; the flag
+as `steps_requested`) with `timed_region_s`.  (A 20-frame region with 7 frames in flight is mostly pipeline fill/drain and measures the
+host, not the GPU.)  Defaults per workload are measured optima (profiles/r03_in_flight.txt): COCO 1 scale 7 frames in flight in batches of
+2, several scales 3 in flight one frame per launch sequence, MPI 10 in flight in batches of 5.
+
+`roofline` (separate pass right after the timed region): HIP event pairs around every launch of the dominant kernel shape, on the stream
+the launch runs on, one batch at a time — roofline_block() below; `parity`: the engine's joints against the full fp32 oracle chain as
+sets of people (parity_report()); `cpu_baseline`: the OpenMP oracle port and torch-CPU conv2d over the same layers.
 
 On one GPU the line also carries `sub_results`: the same engine fed host u8 720p frames through
 rtp_submit_frame (config 2 as written: H2D + device pre-processing inside the timed region), 3 scales
-(config 3, the north-star target), the exact-f32 path, post-processing alone on analytic heat maps.
+(config 3, the north-star target), single-pass fp16, the exact-f32 path, post-processing alone on analytic heat maps.
 """
 import argparse
 import glob
