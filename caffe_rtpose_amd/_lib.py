@@ -35,6 +35,8 @@ class rtp_config(C.Structure):
         ("exec_mode", C.c_int),
         ("split_layers", C.c_char_p),
         ("keep_blobs", C.c_int),
+        ("calibrate_frames", C.c_int),
+        ("calibrate_target", C.c_float),
     ]
 
 
@@ -104,6 +106,17 @@ SIGNATURES = {
     "rtp_plan_summary": (C.c_long, [C.POINTER(rtp_config), C.c_char_p, C.c_size_t]),
     "rtp_kernel_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "rtp_bench_dominant_conv": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_double)]),
+    "rtp_calibrate_precision": (C.c_int, [vp, fp, C.c_int, C.c_float, C.c_char_p, C.c_size_t, fp, fp]),
+    "rtp_calibration_report": (C.c_char_p, [vp]),
+    "rtp_get_split_layers": (C.c_int, [vp, C.c_char_p, C.c_size_t, ip]),
+    "rtp_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "rtp_device_free": (C.c_int, [vp, vp]),
+    "rtp_device_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "rtp_device_synchronize": (C.c_int, [vp]),
+    "rtp_weight_blob_bytes": (C.c_long, [vp]),
+    "rtp_weight_blob_export": (C.c_int, [vp, vp, C.c_size_t]),
+    "rtp_weight_blob_import": (C.c_int, [vp, vp, C.c_size_t]),
+    "rtp_copy_weights_from": (C.c_int, [vp, vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -701,6 +701,7 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
     if constexpr (std::is_same<T, _Float16>::value) {
       if (P.ilv && P.variant == 0) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 0, true>(P, nprob, N, stream);
     }
+#ifdef RTP_EXPERIMENTS  // ablation variants (some compute wrong results on purpose: timing only) exist in librtpose_mi355x_exp.so only
     // experiment variants exist for the dominant plan only (fp16, 7x7, tile 128x64, 256-byte chunks)
     if constexpr (std::is_same<T, _Float16>::value && BM == 128 && BN == 64 && KS == 7 && CHB == 256) {
       switch (P.variant) {
@@ -716,9 +717,14 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
         default: break;
       }
     }
+#endif
     return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true>(P, nprob, N, stream);
   }
-  return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, false>(P, nprob, N, stream);
+#ifdef RTP_EXPERIMENTS
+  return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, MINW, false>(P, nprob, N, stream);  // RTP_RING_SPEC=0: every wave loads and multiplies
+#else
+  return hipErrorInvalidValue;  // the production plan always runs the wave-specialised kernels
+#endif
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int CHB, int SB_, int MINW, bool SPEC, int VAR, bool ILV, bool POOL>
@@ -734,7 +740,7 @@ static hipError_t ring_launch_spec(const ConvParams& P, int nprob, int N, hipStr
     attr_mask.fetch_or(1u << (dev & 31), std::memory_order_relaxed);
   }
   dim3 grid(P.tiles_per_img * N * (P.CoutP / BN) * nprob);
-  static const char* ldsmax = getenv("RTP_RING_LDS_MAX");
+  static const char* ldsmax = RTP_EXP_ENV("RTP_RING_LDS_MAX");
   const int lds = (ldsmax && ldsmax[0] == '1') ? 160 * 1024 : TR::LDS_BYTES;
   hipLaunchKernelGGL(kern, grid, dim3(SPEC ? 512 : 256), lds, stream, P);
   return hipGetLastError();
@@ -745,10 +751,12 @@ static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int npr
   if (chb == 256) {
     if (cfg == CFG_128x32) return ring_launch_one<T, 128, 32, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
     if (cfg == CFG_128x64) {
+#ifdef RTP_EXPERIMENTS
       if constexpr (KS == 7 && std::is_same<T, _Float16>::value) {  // ring-depth experiments (RTP_RING_SB=3/5) on the dominant plan
         if (P.ring_sb == 3) return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 3>(P, nprob, N, stream);
         if (P.ring_sb == 5) return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 5>(P, nprob, N, stream);
       }
+#endif
       return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 256, 4>(P, nprob, N, stream);
     }
     if (cfg == CFG_64x64) {

@@ -200,6 +200,9 @@ struct rtp_engine {
   bool graph_post = false;  // RTP_GRAPH_POST=1: also capture the per-frame post-processing chains + D2H into the batch graph
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
   std::string split_rules;
+  int nctx_full = 1;            // batch contexts of the configured pipeline (a calibration trial runs with one)
+  std::string calib_report;     // what rtp_calibrate_precision last did (rtp_calibration_report)
+  std::vector<void*> user_bufs; // rtp_device_alloc allocations still alive
 };
 
 namespace {
@@ -374,7 +377,7 @@ int build_plan(rtp_engine* e) {
     // 1/8 resolution (85 instead of 88 per row) and 31 instead of 32 M-tiles of 128 per 46x82 image — a launch of the paired
     // 7x7 layers at batch_frames = 2 is 248 workgroups, not 256: it no longer needs EVERY CU at once.
     // The last pixel's far corner tap reads 2 pixels past Hp*Wp: the next image's top halo / the tensor's zero guard.
-    static const char* sh = getenv("RTP_HALO_SHARED");  // experiments: 0 = a halo on both sides of every row
+    static const char* sh = RTP_EXP_ENV("RTP_HALO_SHARED");  // experiments: 0 = a halo on both sides of every row
     const bool shared = !(sh && sh[0] == '0');
     g.Hp = g.H + 2 * g.halo; g.Wp = g.W + (shared ? 1 : 2) * g.halo; g.img_pix = (long)g.Hp * g.Wp;
     e->geom[l] = g;
@@ -525,7 +528,7 @@ int build_plan(rtp_engine* e) {
     else cands = {CFG_128x128, CFG_64x128, CFG_64x64};
     int best = cands.back();
     double best_t = 1e300, best_bytes = 1e300;
-    static const char* tm = getenv("RTP_TILE_RULE");  // experiments: "r2" = round 2's rule
+    static const char* tm = RTP_EXP_ENV("RTP_TILE_RULE");  // experiments: "r2" = round 2's rule
     const bool rule_r2 = tm && !strcmp(tm, "r2");
     long best_wg = -1;
     bool chosen = false;
@@ -559,7 +562,7 @@ int build_plan(rtp_engine* e) {
     // RTP_HALF_CHIP: 1 (default) = where a 128x128 tile gives 100..128 workgroups and the model's choice 129..256, except the dominant
     // shape (whose per-launch efficiency is the figure this path is judged on); 2 = the dominant shape too; 0 = the model alone.
     if (!rule_r2 && ring_ok) {
-      static const char* hc = getenv("RTP_HALF_CHIP");
+      static const char* hc = RTP_EXP_ENV("RTP_HALF_CHIP");
       const int mode = hc ? atoi(hc) : 1;
       const ConvCfgInfo cb = conv_cfg_info(best);
       const long wg_best = ((M + cb.BM - 1) / cb.BM) * e->NI * (round_up(maxcout, cb.BN) / cb.BN) * nprob;
@@ -569,18 +572,29 @@ int build_plan(rtp_engine* e) {
       if (mode > 0 && has128 && best != CFG_128x128 && wg_best > 128 && wg_best <= 256 && wg_128 >= 100 && wg_128 <= 128 && (mode >= 2 || !dominant))
         best = CFG_128x128;
     }
-    if (const char* ov = getenv("RTP_TILE_OVERRIDE")) {  // experiments: "conv2_1=3,conv3_1=3" forces tile ids (kernels.h ConvCfg) per layer
+    if (const char* ov = RTP_EXP_ENV("RTP_TILE_OVERRIDE")) {  // experiments: "conv2_1=3,conv3_1=3" forces tile ids (kernels.h ConvCfg) per layer
       const std::string key = A.name + "=";
-      const char* hit = strstr(ov, key.c_str());
-      if (hit && (hit == ov || hit[-1] == ',')) best = atoi(hit + key.size());
+      for (const char* hit = strstr(ov, key.c_str()); hit; hit = strstr(hit + 1, key.c_str())) {  // "Mconv2_1=.." also contains "conv2_1=": take the entry that starts at a boundary
+        if (!(hit == ov || hit[-1] == ',')) continue;
+        const int v = atoi(hit + key.size());
+        if (std::find(cands.begin(), cands.end(), v) == cands.end())
+          return fail(e, RTP_EINVAL, "RTP_TILE_OVERRIDE: tile id %d is not a candidate for layer %s", v, A.name.c_str());
+        best = v;
+        break;
+      }
     }
     {
-      static const char* fc = getenv("RTP_FORCE_CFG");  // experiments only: force a tile for the k x k layers at 1/8 resolution
-      static const char* kd = getenv("RTP_FORCE_CFG_KEEP_DOM");  // 1: ... except the dominant shape (7x7, 128 input channels)
-      if (fc && ring_ok && A.level == 3 && maxcout > 64 && !(kd && kd[0] == '1' && A.k_eff == 7 && A.cin == 128)) best = atoi(fc);
+      static const char* fc = RTP_EXP_ENV("RTP_FORCE_CFG");  // experiments only: force a tile for the k x k layers at 1/8 resolution
+      static const char* kd = RTP_EXP_ENV("RTP_FORCE_CFG_KEEP_DOM");  // 1: ... except the dominant shape (7x7, 128 input channels)
+      if (fc && ring_ok && A.level == 3 && maxcout > 64 && !(kd && kd[0] == '1' && A.k_eff == 7 && A.cin == 128)) {
+        const int v = atoi(fc);
+        if (std::find(cands.begin(), cands.end(), v) == cands.end())
+          return fail(e, RTP_EINVAL, "RTP_FORCE_CFG: tile id %d is not a candidate for layer %s", v, A.name.c_str());
+        best = v;
+      }
     }
     const ConvCfgInfo ci = conv_cfg_info(best);
-    const char* force = getenv("RTP_CONV_IMPL");
+    const char* force = RTP_EXP_ENV("RTP_CONV_IMPL");
     const bool allow_ring = !(force && !strcmp(force, "v1"));
     for (int idx : {s.a, s.b}) {
       if (idx < 0) continue;
@@ -590,7 +604,7 @@ int build_plan(rtp_engine* e) {
       c.impl = 0;
       if (allow_ring && !c.first && (c.k_eff == 3 || c.k_eff == 7)) {
         const int row_bytes = c.Cin_p * e->elem;
-        static const char* f128 = getenv("RTP_RING_CHB128");
+        static const char* f128 = RTP_EXP_ENV("RTP_RING_CHB128");
         int chb = ((best == CFG_64x64 || best == CFG_128x64 || best == CFG_128x32) && row_bytes % 256 == 0 && !(f128 && f128[0] == '1')) ? 256 : 128;
         if (best == CFG_128x32 && chb != 256) { best = CFG_64x64; c.cfg = best; c.CoutP = round_up(maxcout, 64); chb = 128; }
         if (row_bytes % chb == 0) {
@@ -622,7 +636,7 @@ int build_plan(rtp_engine* e) {
   // runs on a ring kernel with 128-pixel tiles of 128-byte chunks (the trunk's conv1_2 / conv2_2 / conv3_4), even resolution.
   // The un-pooled blob is then never written (rtp_config.keep_blobs = 1 keeps every blob tappable and pools in its own launch).
   {
-    static const char* fp = getenv("RTP_FUSE_POOL");  // experiments: 0 = stand-alone pooling launches
+    static const char* fp = RTP_EXP_ENV("RTP_FUSE_POOL");  // experiments: 0 = stand-alone pooling launches
     for (size_t si = 1; si < e->steps.size() && !e->cfg.keep_blobs && !(fp && fp[0] == '0'); ++si) {
       if (e->steps[si].type != 2 || e->steps[si - 1].type != 1 || e->steps[si - 1].b >= 0) continue;
       const int pi = e->steps[si].a;
@@ -641,7 +655,7 @@ int build_plan(rtp_engine* e) {
     }
   }
   {  // the input convolution without the im2col tensor: fp16 storage, 64 channels, one plain destination
-    static const char* fd = getenv("RTP_FIRST_DIRECT");  // experiments: 0 = the pack + 1x1 route
+    static const char* fd = RTP_EXP_ENV("RTP_FIRST_DIRECT");  // experiments: 0 = the pack + 1x1 route
     for (size_t si = 0; si + 1 < e->steps.size() && !(fd && fd[0] == '0'); ++si) {
       const Step& s1 = e->steps[si];
       if (s1.type != 1 || s1.b >= 0 || !e->convs[s1.a].first) continue;
@@ -661,7 +675,7 @@ int build_plan(rtp_engine* e) {
   }
   // branch tails: 1x1 (ReLU) -> 1x1 with nobody else reading the middle blob become ONE launch (conv_pw2.hip)
   {
-    static const char* nf = getenv("RTP_FUSE_1X1");
+    static const char* nf = RTP_EXP_ENV("RTP_FUSE_1X1");
     const bool allow = e->prec == 0 && !(nf && nf[0] == '0');
     for (size_t si = 0; allow && si + 1 < e->steps.size(); ++si) {
       Step& s1 = e->steps[si];
@@ -684,6 +698,7 @@ int build_plan(rtp_engine* e) {
   // arena layout
   size_t off = 0;
   for (auto& t : e->tensors) {
+    if (!t.written) { t.offset = 0; continue; }  // fused away (its convolution pools in the epilogue): never read, never written, no space
     const Geom& g = e->geom[t.level];
     const size_t pix_bytes = (size_t)t.stride() * e->elem;
     off = round_up_sz(off, 256);
@@ -712,11 +727,11 @@ int build_plan(rtp_engine* e) {
   e->dominant_step = -1;
   for (size_t si = 0; si < e->steps.size(); ++si) {
     const Step& s = e->steps[si];
-    static const char* dq = getenv("RTP_DOMINANT_Q");  // profiling: 1 = probe the first fp8-compensated launch of that shape instead (stage 4)
+    static const char* dq = RTP_EXP_ENV("RTP_DOMINANT_Q");  // profiling: 1 = probe the first fp8-compensated launch of that shape instead (stage 4)
     if (s.type == 1 && e->convs[s.a].k == 7 && e->convs[s.a].cin == 128 && (!(dq && dq[0] == '1') || e->convs[s.a].h8)) { e->dominant_step = (int)si; break; }
   }
   e->strip_rows = e->N > 1 ? 16 : 8;  // several scales: the row interpolations of a strip are the larger share, taller strips amortise them (+3 % frames/s at 3 scales)
-  if (const char* sr = getenv("RTP_NMS_STRIP_ROWS")) { const int v = atoi(sr); if (v >= 2 && v <= 16) e->strip_rows = v; }  // experiments
+  if (const char* sr = RTP_EXP_ENV("RTP_NMS_STRIP_ROWS")) { const int v = atoi(sr); if (v >= 2 && v <= 16) e->strip_rows = v; }  // experiments
   // the strip kernel keeps (strip_rows + 2 + NMSF_TROWS) rows of W floats + a W x 8-byte column table in LDS (postproc.hip, 150 KiB cap)
   while (e->strip_rows > 2 && ((size_t)(e->strip_rows + 2 + 8 /* NMSF_TROWS */) * e->cfg.net_w * 4 + (size_t)e->cfg.net_w * 8) > 150 * 1024) e->strip_rows /= 2;
   if (((size_t)(e->strip_rows + 2 + 8 /* NMSF_TROWS */) * e->cfg.net_w * 4 + (size_t)e->cfg.net_w * 8) > 150 * 1024)
@@ -936,17 +951,17 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   P.clkprobe = g_clkprobe;
   P.nimg = nimg;
   {
-    static const char* rot = getenv("RTP_CONV_ROTATE");
+    static const char* rot = RTP_EXP_ENV("RTP_CONV_ROTATE");
     P.rotate = (rot && rot[0] == '0') ? 0 : 1;
-    static const char* xm = getenv("RTP_CONV_XCDMAP");
+    static const char* xm = RTP_EXP_ENV("RTP_CONV_XCDMAP");
     P.xcdmap = (xm && xm[0] == '0') ? 0 : 1;
-    static const char* sb = getenv("RTP_RING_SB");
+    static const char* sb = RTP_EXP_ENV("RTP_RING_SB");
     P.ring_sb = sb ? atoi(sb) : 6;
-    static const char* sp = getenv("RTP_RING_SPEC");
+    static const char* sp = RTP_EXP_ENV("RTP_RING_SPEC");
     P.spec = (sp && sp[0] == '0') ? 0 : 1;  // wave-specialised ring kernels (default); 0 = every wave does both
-    static const char* rv = getenv("RTP_RING_VAR");
+    static const char* rv = RTP_EXP_ENV("RTP_RING_VAR");
     P.variant = rv ? atoi(rv) : 0;
-    static const char* il = getenv("RTP_RING_ILV");
+    static const char* il = RTP_EXP_ENV("RTP_RING_ILV");
     // interleaved A-fragment rows (conv_ring.hip ILV; bit-identical): default for the fp8-compensated launches, whose plain variant
     // spills 6 registers (44.6 vs 45.3 us on the dominant shape); the plain fp16 launches are faster without.  "1" = all, "0" = none
     P.ilv = il ? (il[0] == '1' || (il[0] == 'q' && A.h8) || (il[0] == '7' && A.h8 && A.k_eff == 7)) : (A.h8 ? 1 : 0);
@@ -991,7 +1006,7 @@ int launch_pw2_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   Q.split_w1 = A.split_w ? 1 : 0;
   Q.split_w2 = C.split_w ? 1 : 0;
   Q.h_lo = C.split_a ? 1 : 0;
-  static const char* probe = getenv("RTP_PW2_PROBE");  // diagnostics (eager mode only): phase stamps of workgroup 0
+  static const char* probe = RTP_EXP_ENV("RTP_PW2_PROBE");  // diagnostics (eager mode only): phase stamps of workgroup 0
   static int probed = 0;
   hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
   if (probe) (void)hipStreamIsCapturing(cx.stream, &cst);
@@ -1146,9 +1161,9 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
   for (int j = 0; j < nframes; ++j) {
     Slot& sl = cx.slot[j];
     if (sl.stream != cx.stream) HIPCHK(e, hipStreamWaitEvent(sl.stream, cx.ev[1], 0));
-    static const char* diag = getenv("RTP_DIAG_SKIP_POST");  // diagnosis only: 1 = no connect, 2 = no post-processing at all (both through the
+    static const char* diag = RTP_EXP_ENV("RTP_DIAG_SKIP_POST");  // diagnosis only: 1 = no connect, 2 = no post-processing at all (both through the
     const int skip = diag ? atoi(diag) : 0;                  // materialised map); 3..6 = production kernels: 3 nms only, 4 + pairs, 5 + match, 6 all
-    static const char* unf = getenv("RTP_POST_UNFUSED");  // experiments: production path through the materialised map
+    static const char* unf = RTP_EXP_ENV("RTP_POST_UNFUSED");  // experiments: production path through the materialised map
     HIPCHK(e, hipEventRecord(sl.ev[0], sl.stream));
     if (skip >= 3) {
       const ResizeParams rp = resize_params(e, cx, j);
@@ -1220,8 +1235,8 @@ int capture_batch(rtp_engine* e, Ctx& cx, int nframes, hipGraphExec_t* out) {
 
 int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize = false) {
   int rc;
-  static const char* diag = getenv("RTP_DIAG_SKIP_POST");
-  static const char* unf = getenv("RTP_POST_UNFUSED");
+  static const char* diag = RTP_EXP_ENV("RTP_DIAG_SKIP_POST");
+  static const char* unf = RTP_EXP_ENV("RTP_POST_UNFUSED");
   // (a timing pass launches eagerly: its event pairs sit between the launches)
   const bool graph = e->use_graph && !e->time_dominant && !materialize && input_dev == cx.input && !e->cfg.render && !diag && !unf && nframes <= 16;
   cx.graph_run = graph;
@@ -1245,13 +1260,13 @@ int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bo
 }
 int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev, bool materialize = false) { return launch_batch(e, cx, 1, input_dev, materialize); }
 
-// experiments: RTP_CONV_PRIO / RTP_POST_PRIO = a stream priority (hipDeviceGetStreamPriorityRange: lower number = higher priority)
-// for the batch (conv stack) streams / the per-frame post-processing streams; unset = default-priority streams
-hipError_t make_stream(hipStream_t* s, const char* env_name) {
-  // RTP_POST_CUS = n: the post-processing streams may only use n CUs (hipExtStreamCreateWithCUMask; the KFD interleaves the
-  // mask bits over the XCDs, so the low 8 bits are one CU in each of the 8 XCDs).  With the shared-halo geometry a convolution
-  // launch at 1/8 resolution is 248 workgroups: 8 CUs can belong to other frames' post-processing without costing it a second round.
-  if (!strcmp(env_name, "RTP_POST_PRIO")) {
+// Streams of the batch contexts (post = false) and of the per-frame post-processing chains (post = true).
+// Experiments build only: RTP_CONV_PRIO / RTP_POST_PRIO = a stream priority (hipDeviceGetStreamPriorityRange: lower number = higher
+// priority); RTP_POST_CUS = n: the post-processing streams may only use n CUs (hipExtStreamCreateWithCUMask; the KFD interleaves the
+// mask bits over the XCDs, so the low 8 bits are one CU in each of the 8 XCDs).  Both measured worse than plain streams.
+hipError_t make_stream(hipStream_t* s, bool post) {
+#ifdef RTP_EXPERIMENTS
+  if (post) {
     const char* c = getenv("RTP_POST_CUS");
     const int n = c ? atoi(c) : 0;
     if (n > 0 && n < 256) {
@@ -1260,19 +1275,23 @@ hipError_t make_stream(hipStream_t* s, const char* env_name) {
       return hipExtStreamCreateWithCUMask(s, 8, mask);
     }
   }
-  const char* v = getenv(env_name);
-  if (!v || !v[0]) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-  int least = 0, greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  int pr = atoi(v);
-  pr = std::max(greatest, std::min(least, pr));
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, pr);
+  const char* v = getenv(post ? "RTP_POST_PRIO" : "RTP_CONV_PRIO");
+  if (v && v[0]) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    int pr = atoi(v);
+    pr = std::max(greatest, std::min(least, pr));
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, pr);
+  }
+#endif
+  (void)post;
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
 int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   if (sl.preset_stream) {}  // RTP_STREAM_PLAN: alloc_ctx chose it
   else if (share_stream) sl.stream = cx.stream;
-  else { HIPCHK(e, make_stream(&sl.stream, "RTP_POST_PRIO")); sl.own_stream = true; }
+  else { HIPCHK(e, make_stream(&sl.stream, true)); sl.own_stream = true; }
   const size_t res_floats = (size_t)e->heat_channels * e->cfg.net_h * e->cfg.net_w;
   HIPCHK(e, hipMalloc((void**)&sl.resized, res_floats * sizeof(float)));
   const size_t peak_floats = (size_t)e->num_parts * (e->max_peaks + 1) * 3;
@@ -1302,7 +1321,7 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   // streams per context so that conv stacks alternate between queues 0 / 1 and BOTH post-processing chains of a batch sit on queues
   // 2 / 3: no post chain ever stands in front of another context's conv stack.  (Default: conv stream, then the extra slots' streams:
   // with batches of 2 the conv stacks share queues 0 / 2 with frame 0's chains, frame 1's chains use queues 1 / 3.)
-  static const char* plan = getenv("RTP_STREAM_PLAN");
+  static const char* plan = RTP_EXP_ENV("RTP_STREAM_PLAN");
   const bool planned = plan && plan[0] == '1' && e->B == 2;
   std::vector<hipStream_t> planned_streams;
   if (planned) {
@@ -1313,7 +1332,7 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
     cx.spare_stream = q[(ci & 1) ^ 1];
     planned_streams = {q[2], q[3]};
   } else
-  HIPCHK(e, make_stream(&cx.stream, "RTP_CONV_PRIO"));
+  HIPCHK(e, make_stream(&cx.stream, false));
   HIPCHK(e, hipMalloc((void**)&cx.arena, e->arena_bytes));
   HIPCHK(e, hipMemset(cx.arena, 0, e->arena_bytes));
   const size_t in_floats = (size_t)e->NI * 3 * e->cfg.net_h * e->cfg.net_w;
@@ -1327,7 +1346,7 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   cx.slot.resize(e->B);
   for (int j = 0; j < e->B; ++j) {
     int rc;
-    static const char* own0 = getenv("RTP_POST_OWN0");  // experiments: 1 = frame 0's post-processing chain also gets its own stream
+    static const char* own0 = RTP_EXP_ENV("RTP_POST_OWN0");  // experiments: 1 = frame 0's post-processing chain also gets its own stream
     if (planned) {
       cx.slot[j].stream = planned_streams[j];
       cx.slot[j].own_stream = true;
@@ -1336,7 +1355,7 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
     if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0 && !(own0 && own0[0] == '1')))) return rc;
   }
   {
-    static const char* sh1 = getenv("RTP_POST_SHARE1");  // experiments: 1 = frame 0's chain runs on frame 1's stream (behind nothing of the conv queues)
+    static const char* sh1 = RTP_EXP_ENV("RTP_POST_SHARE1");  // experiments: 1 = frame 0's chain runs on frame 1's stream (behind nothing of the conv queues)
     if (sh1 && sh1[0] == '1' && e->B >= 2 && !planned && cx.slot[0].stream == cx.stream) cx.slot[0].stream = cx.slot[1].stream;
   }
   return RTP_OK;
@@ -1457,6 +1476,70 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
   return RTP_OK;
 }
 
+// Device state of the current plan: weight arena (packed + uploaded from w_ref / b_ref), `nctx` batch contexts, the dry run
+// warmup() does (rtpose.cpp:233; it also sets the kernels' LDS attributes), and — `capture` — the full-batch graph of every context.
+int materialize_plan(rtp_engine* e, int nctx, bool capture) {
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  {
+    hipError_t s = hipMalloc((void**)&e->dweights, e->weights_bytes);
+    if (s != hipSuccess) { e->dweights = nullptr; return fail(e, RTP_ENOMEM, "hipMalloc(%zu) for weights failed: %s", e->weights_bytes, hipGetErrorString(s)); }
+    s = hipMemset(e->dweights, 0, e->weights_bytes);
+    if (s != hipSuccess) return fail(e, RTP_EHIP, "hipMemset failed: %s", hipGetErrorString(s));
+    if (!e->dchmap) {
+      s = hipMalloc((void**)&e->dchmap, 4096 * sizeof(int));
+      if (s != hipSuccess) return fail(e, RTP_ENOMEM, "hipMalloc failed");
+    }
+  }
+  compute_wq_exp(e);
+  for (size_t i = 0; i < e->convs.size(); ++i)
+    if ((rc = upload_conv_weights(e, (int)i))) return rc;
+  e->ctx.resize(nctx);
+  for (auto& c : e->ctx)
+    if ((rc = alloc_ctx(e, c))) return rc;
+  {
+    Ctx& cx = e->ctx[0];
+    const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+    HIPCHK(e, hipMemsetAsync(cx.input, 0, in_floats * sizeof(float), cx.stream));
+    if ((rc = launch_batch_body(e, cx, 1, cx.input, false, false))) return rc;  // eager: also sets the kernels' LDS attributes
+    hipError_t s = hipStreamSynchronize(cx.stream);
+    if (s != hipSuccess) return fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s));
+    for (Slot& sl : cx.slot) {
+      s = hipStreamSynchronize(sl.stream);
+      if (s != hipSuccess) return fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s));
+    }
+  }
+  if (capture && e->use_graph && !e->cfg.render)  // capture the full-batch plan of every context now, not inside the first frames
+    for (auto& c : e->ctx)
+      if ((rc = capture_batch(e, c, e->B, &c.gexec[e->B]))) return rc;
+  return RTP_OK;
+}
+
+// Drop the plan and everything on the device that was laid out for it; the reference weights (w_ref / b_ref), thresholds, scales and
+// the pre-processing tables stay.
+void drop_plan(rtp_engine* e) {
+  (void)hipSetDevice(e->cfg.device_id);
+  (void)hipDeviceSynchronize();
+  for (auto& c : e->ctx) free_ctx(c);
+  e->ctx.clear();
+  if (e->dweights) { (void)hipFree(e->dweights); e->dweights = nullptr; }
+  e->tensors.clear(); e->blob_tensor.clear(); e->blob_dims.clear(); e->convs.clear(); e->steps.clear(); e->pools.clear();
+  e->open_ctx = -1;
+  e->fifo.clear();
+}
+
+// Re-plan an idle engine for another precision mode / split set (load-time calibration).  light = one context, no graph capture.
+int replan(rtp_engine* e, int mode, const std::string& rules, bool light) {
+  drop_plan(e);
+  e->mode = mode;
+  e->prec = mode == RTP_PREC_FP32 ? 1 : 0;
+  e->elem = e->prec ? 4 : 2;
+  e->split_rules = rules;
+  int rc = build_plan(e);
+  if (rc) return rc;
+  return materialize_plan(e, light ? 1 : e->nctx_full, !light);
+}
+
 // ---- batching: frames are staged into the open context; a full batch is launched at once ----------
 int open_slot(rtp_engine* e, int* ci, int* sj) {
   if (e->open_ctx < 0) {
@@ -1512,6 +1595,8 @@ int rtp_config_default(rtp_config* cfg) {
   cfg->frames_in_flight = 2;
   cfg->batch_frames = 1;
   cfg->exec_mode = RTP_EXEC_GRAPH;
+  cfg->calibrate_frames = 0;
+  cfg->calibrate_target = 0.7e-3f;
   return RTP_OK;
 }
 
@@ -1527,6 +1612,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   if (e->dchmap) (void)hipFree(e->dchmap);
   for (hipEvent_t ev : e->tev) if (ev) (void)hipEventDestroy(ev);
   if (e->prep_tables) (void)hipFree(e->prep_tables);
+  for (void* p : e->user_bufs) if (p) (void)hipFree(p);
   delete e;
 }
 
@@ -1566,7 +1652,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   e->prec = cfg->precision == RTP_PREC_FP32 ? 1 : 0;
   e->elem = e->prec ? 4 : 2;
   {
-    const char* sr = getenv("RTP_SPLIT_LAYERS");  // experiments: override the split set of RTP_PREC_MIXED
+    const char* sr = RTP_EXP_ENV("RTP_SPLIT_LAYERS");  // experiments: override the split set of RTP_PREC_MIXED
     e->split_rules = sr ? sr : (cfg->split_layers ? cfg->split_layers : kDefaultSplit);
     e->cfg.split_layers = nullptr;
   }
@@ -1576,13 +1662,13 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   e->start_scale = cfg->start_scale;
   e->scale_gap = cfg->scale_gap;
   {
-    const char* eg = getenv("RTP_EXEC");  // experiments: override the execution mode ("eager" / "graph")
+    const char* eg = getenv("RTP_EXEC");  // the ONE environment variable the production library reads: "eager" / "graph" override rtp_config.exec_mode (same results either way)
     e->use_graph = cfg->exec_mode == RTP_EXEC_GRAPH;
     if (eg && !strcmp(eg, "eager")) e->use_graph = false;
     if (eg && !strcmp(eg, "graph")) e->use_graph = true;
-    const char* f8 = getenv("RTP_SPLIT_FP8");
+    const char* f8 = RTP_EXP_ENV("RTP_SPLIT_FP8");
     e->split_fp8 = !(f8 && f8[0] == '0');
-    const char* gp = getenv("RTP_GRAPH_POST");
+    const char* gp = RTP_EXP_ENV("RTP_GRAPH_POST");
     e->graph_post = gp && gp[0] == '1';
   }
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
@@ -1628,39 +1714,13 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     }
   }
 
-  if ((rc = use_device(e))) return bail(rc);
-  {
-    hipError_t s = hipMalloc((void**)&e->dweights, e->weights_bytes);
-    if (s != hipSuccess) return bail(fail(e, RTP_ENOMEM, "hipMalloc(%zu) for weights failed: %s", e->weights_bytes, hipGetErrorString(s)));
-    s = hipMemset(e->dweights, 0, e->weights_bytes);
-    if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "hipMemset failed: %s", hipGetErrorString(s)));
-    s = hipMalloc((void**)&e->dchmap, 4096 * sizeof(int));
-    if (s != hipSuccess) return bail(fail(e, RTP_ENOMEM, "hipMalloc failed"));
-  }
-  compute_wq_exp(e);
-  for (size_t i = 0; i < e->convs.size(); ++i)
-    if ((rc = upload_conv_weights(e, (int)i))) return bail(rc);
-  e->ctx.resize((cfg->frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0));  // batches in flight (+1 being filled)
-  for (auto& c : e->ctx)
-    if ((rc = alloc_ctx(e, c))) return bail(rc);
+  e->nctx_full = (cfg->frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0);  // batches in flight (+1 being filled)
+  if ((rc = materialize_plan(e, e->nctx_full, true))) return bail(rc);
   if ((rc = build_prep_tables(e))) return bail(rc);
-  // dry run, as warmup() does (rtpose.cpp:233)
-  {
-    Ctx& cx = e->ctx[0];
-    const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
-    hipError_t s = hipMemsetAsync(cx.input, 0, in_floats * sizeof(float), cx.stream);
-    if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "hipMemsetAsync failed"));
-    if ((rc = launch_batch_body(e, cx, 1, cx.input, false, false))) return bail(rc);  // eager: also sets the kernels' LDS attributes
-    s = hipStreamSynchronize(cx.stream);
-    if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s)));
-    for (Slot& sl : cx.slot) {
-      s = hipStreamSynchronize(sl.stream);
-      if (s != hipSuccess) return bail(fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s)));
-    }
+  if (cfg->calibrate_frames > 0 && e->mode == RTP_PREC_MIXED) {   // load-time precision calibration (net.cpp:750-803 is where real weights arrive)
+    float before = 0.f, after = 0.f;
+    if ((rc = rtp_calibrate_precision(e, nullptr, cfg->calibrate_frames, cfg->calibrate_target, nullptr, 0, &before, &after))) return bail(rc);
   }
-  if (e->use_graph && !e->cfg.render)  // capture the full-batch plan of every context now, not inside the first frames
-    for (auto& c : e->ctx)
-      if ((rc = capture_batch(e, c, e->B, &c.gexec[e->B]))) return bail(rc);
   *out = e;
   return RTP_OK;
 }
@@ -1926,7 +1986,7 @@ int rtp_post_from_lowres(rtp_engine* e, const float* lowres, float* peaks, float
   const size_t pbytes = (size_t)e->num_parts * (e->max_peaks + 1) * 3 * sizeof(float);
   HIPCHK(e, hipMemcpy(cx.lowres, lowres, (size_t)e->N * e->heat_channels * e->low_h * e->low_w * sizeof(float), hipMemcpyHostToDevice));
   if (peaks) HIPCHK(e, hipMemcpy(sl.peaks, peaks, pbytes, hipMemcpyHostToDevice));  // stale slots stay, like the reference's blob
-  if (getenv("RTP_NMS_PROBE")) {  // diagnostics: phase stamps of the middle strip workgroup of part 0
+  if (RTP_EXP_ENV("RTP_NMS_PROBE")) {  // diagnostics: phase stamps of the middle strip workgroup of part 0
     unsigned long long* d = nullptr;
     HIPCHK(e, hipMalloc((void**)&d, 32 * 8));
     HIPCHK(e, hipMemset(d, 0, 32 * 8));
@@ -2253,9 +2313,9 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   e->prec = cfg->precision == RTP_PREC_FP32 ? 1 : 0;
   e->elem = e->prec ? 4 : 2;
   {
-    const char* sr = getenv("RTP_SPLIT_LAYERS");
+    const char* sr = RTP_EXP_ENV("RTP_SPLIT_LAYERS");
     e->split_rules = sr ? sr : (cfg->split_layers ? cfg->split_layers : kDefaultSplit);
-    const char* f8 = getenv("RTP_SPLIT_FP8");
+    const char* f8 = RTP_EXP_ENV("RTP_SPLIT_FP8");
     e->split_fp8 = !(f8 && f8[0] == '0');
   }
   e->N = cfg->num_scales;
@@ -2456,7 +2516,7 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   for (int i = 0; i < iters; ++i) if ((rc = launch_conv_step(e, cx, s, e->NI))) return rc;
   HIPCHK(e, hipEventRecord(cx.ev[1], cx.stream));
   HIPCHK(e, hipEventSynchronize(cx.ev[1]));
-  if (getenv("RTP_CLKPROBE")) {  // diagnostics: effective shader clock while this kernel runs back to back
+  if (RTP_EXP_ENV("RTP_CLKPROBE")) {  // diagnostics: effective shader clock while this kernel runs back to back
     unsigned long long* d = nullptr;
     HIPCHK(e, hipMalloc((void**)&d, 16));
     HIPCHK(e, hipMemset(d, 0, 16));
@@ -2480,6 +2540,244 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   for (int idx : {s.a, s.b}) if (idx >= 0) { const ConvOp& c = e->convs[idx]; fl += 2.0 * c.cout * c.cin * c.k * c.k * (double)g.H * g.W * e->NI; }
   (void)nprob;
   if (flops_per_launch) *flops_per_launch = fl;
+  return RTP_OK;
+}
+
+// ---- caller-owned device buffers ------------------------------------------------------------------
+// Replaces: blobs()[0]->mutable_gpu_data() as the H2D target a caller fills itself (rtpose.cpp:1131): a device buffer on the ENGINE's
+// device from the ENGINE's HIP runtime, for rtp_submit_device.  (A process that also loads another HIP runtime — torch's wheel bundles
+// its own — must not hand that runtime's pointers to this library and expect the two to agree about streams; bench.py allocates here.)
+int rtp_device_alloc(rtp_engine* e, size_t bytes, void** dptr) {
+  if (!e || !dptr || bytes == 0) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  void* p = nullptr;
+  const hipError_t s = hipMalloc(&p, bytes);
+  if (s != hipSuccess) return fail(e, RTP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(s));
+  e->user_bufs.push_back(p);
+  *dptr = p;
+  return RTP_OK;
+}
+int rtp_device_free(rtp_engine* e, void* dptr) {
+  if (!e || !dptr) return RTP_EINVAL;
+  auto it = std::find(e->user_bufs.begin(), e->user_bufs.end(), dptr);
+  if (it == e->user_bufs.end()) return fail(e, RTP_EINVAL, "rtp_device_free: not a buffer of this engine");
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  e->user_bufs.erase(it);
+  HIPCHK(e, hipFree(dptr));
+  return RTP_OK;
+}
+int rtp_device_upload(rtp_engine* e, void* dst_device, const void* src_host, size_t bytes) {
+  if (!e || !dst_device || !src_host) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  HIPCHK(e, hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+  return RTP_OK;
+}
+int rtp_device_synchronize(rtp_engine* e) {
+  if (!e) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  HIPCHK(e, hipDeviceSynchronize());
+  return RTP_OK;
+}
+
+// ---- load-time precision calibration ----------------------------------------------------------------
+// The default split set of RTP_PREC_MIXED was chosen on one synthetic weight set.  Trained weights arrive through
+// CopyTrainedLayersFrom (net.cpp:750-803) with another spectrum; this measures the set on the weights that are LOADED:
+//   reference  = the same frames through RTP_PREC_F16X3 (every layer as hi + lo fp16 pairs: 1e-5 of the map maximum vs fp32),
+//   candidate  = the current mixed plan;  err = max |candidate - reference| / max |reference|  over the final maps.
+// While err > target, every layer group that is not split yet is tried on top of the current set and the one that lowers the
+// error most is promoted; when every group is in and the error still exceeds the target the engine falls back to F16X3.
+int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes, float target, char* rules_out, size_t rules_len,
+                            float* err_before, float* err_after) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (e->mode != RTP_PREC_MIXED) return fail(e, RTP_EINVAL, "rtp_calibrate_precision adjusts the split set of RTP_PREC_MIXED (engine precision is %d)", e->mode);
+  if (nframes < 1 || nframes > 64) return fail(e, RTP_EINVAL, "calibration frames %d out of range [1, 64]", nframes);
+  if (!(target > 0.f)) target = 0.7e-3f;
+  const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+  const size_t low_floats = (size_t)e->N * e->heat_channels * e->low_h * e->low_w;
+  std::vector<float> synth;
+  if (!frames_host) {  // what process_and_pad_image makes of a u8 frame: v / 256 - 0.5 (rtpose.cpp:259), seeded
+    synth.resize(in_floats * nframes);
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ e->cfg.synthetic_seed;
+    for (float& v : synth) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = (float)((st >> 56) & 0xff) / 256.0f - 0.5f; }
+    frames_host = synth.data();
+  }
+  std::vector<float> ref(low_floats * nframes), got(low_floats);
+  auto run = [&](const float* x, float* out) { return rtp_forward_heatmaps(e, x, out); };
+  const std::string base_rules = e->split_rules;
+  // reference maps
+  if ((rc = replan(e, RTP_PREC_F16X3, base_rules, true))) return rc;
+  for (int f = 0; f < nframes; ++f)
+    if ((rc = run(frames_host + (size_t)f * in_floats, ref.data() + (size_t)f * low_floats))) return rc;
+  double norm = 0;
+  for (float v : ref) norm = std::max(norm, (double)std::fabs(v));
+  if (!(norm > 0) || !std::isfinite(norm)) {
+    (void)replan(e, RTP_PREC_MIXED, base_rules, false);
+    return fail(e, RTP_ERANGE, "calibration: the reference maps are %s (weights / frames out of range for fp16 storage?)", norm > 0 ? "not finite" : "all zero");
+  }
+  auto measure = [&](double* err) -> int {
+    double m = 0;
+    for (int f = 0; f < nframes; ++f) {
+      int r2 = run(frames_host + (size_t)f * in_floats, got.data());
+      if (r2) return r2;
+      const float* rf = ref.data() + (size_t)f * low_floats;
+      for (size_t i = 0; i < low_floats; ++i) {
+        const double d = std::fabs((double)got[i] - (double)rf[i]);
+        m = (d == d) ? std::max(m, d) : 1e30;   // NaN counts as unbounded
+      }
+    }
+    *err = m / norm;
+    return RTP_OK;
+  };
+  // the layer groups a rule can promote: trunk blocks by their "convN_" prefix, stage 1, the refinement stages
+  std::vector<std::string> groups;
+  {
+    std::vector<std::string> all;
+    auto add = [&](const std::string& g) { if (std::find(all.begin(), all.end(), g) == all.end()) all.push_back(g); };
+    for (auto& c : e->convs) {
+      const size_t st = c.name.find("_stage");
+      if (st != std::string::npos) { size_t en = st + 6; while (en < c.name.size() && isdigit((unsigned char)c.name[en])) ++en; add("*" + c.name.substr(st, en - st) + "_"); }
+      else { const size_t us = c.name.find('_'); add(us == std::string::npos ? c.name : c.name.substr(0, us + 1)); }
+    }
+    for (auto& g : all) {   // groups with at least one layer that is not fully split yet
+      bool open = false;
+      for (auto& c : e->convs) {
+        const bool in_g = g[0] == '*' ? c.name.find(g.substr(1)) != std::string::npos : c.name.compare(0, g.size(), g) == 0;
+        if (in_g && !(c.split_w && (c.split_a || c.first))) open = true;
+      }
+      if (open) groups.push_back(g);
+    }
+  }
+  std::ostringstream rep;
+  std::string rules = base_rules;
+  double err = 0;
+  if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return rc;
+  if ((rc = measure(&err))) return rc;
+  if (err_before) *err_before = (float)err;
+  rep << "target " << target << "; frames " << nframes << "; set \"" << rules << "\" err " << err;
+  bool last_is_current = true;
+  while (err > target && !groups.empty()) {
+    int best = -1;
+    double best_err = 1e300;
+    for (size_t g = 0; g < groups.size(); ++g) {
+      double eg = 0;
+      if ((rc = replan(e, RTP_PREC_MIXED, rules + "," + groups[g], true))) return rc;
+      if ((rc = measure(&eg))) return rc;
+      rep << "; try +" << groups[g] << " -> " << eg;
+      if (eg < best_err) { best_err = eg; best = (int)g; }
+    }
+    rules += "," + groups[best];
+    rep << "; promote " << groups[best];
+    last_is_current = (best == (int)groups.size() - 1);
+    groups.erase(groups.begin() + best);
+    err = best_err;
+  }
+  (void)last_is_current;
+  int final_mode = RTP_PREC_MIXED;
+  if (err > target) {   // every group is split and the fp8-compensated set still misses the target: every layer as three fp16 passes
+    final_mode = RTP_PREC_F16X3;
+    rep << "; every group promoted, err " << err << " > target: falling back to RTP_PREC_F16X3";
+    err = 0;
+  }
+  if ((rc = replan(e, final_mode, rules, false))) return rc;
+  if (final_mode == RTP_PREC_MIXED && (rc = measure(&err))) return rc;
+  if (err_after) *err_after = (float)err;
+  rep << "; final " << (final_mode == RTP_PREC_MIXED ? "mixed" : "f16x3") << " set \"" << rules << "\" err " << err;
+  e->calib_report = rep.str();
+  if (rules_out && rules_len) snprintf(rules_out, rules_len, "%s", final_mode == RTP_PREC_MIXED ? rules.c_str() : "@f16x3");
+  return RTP_OK;
+}
+const char* rtp_calibration_report(const rtp_engine* e) { return e ? e->calib_report.c_str() : ""; }
+// The split set in force (rule list of rtp_config.split_layers syntax) and the precision mode (a calibration may have changed both).
+int rtp_get_split_layers(const rtp_engine* e, char* buf, size_t buflen, int* precision) {
+  if (!e) return RTP_EINVAL;
+  if (buf && buflen) snprintf(buf, buflen, "%s", e->split_rules.c_str());
+  if (precision) *precision = e->mode;
+  return RTP_OK;
+}
+
+// ---- one-time weight distribution (optional; nothing here is on the per-frame path) -------------------------
+// The reference reads the .caffemodel once per GPU thread (rtpose.cpp:183-184: NUM_GPU disk reads + NUM_GPU H2D copies).  The engine
+// packs weights into its kernels' staging order on the host, which costs more than the read.  Worker 0 does that once; the others take
+// the PACKED arena: rtp_copy_weights_from over xGMI inside one process (rtpose.bin --share_weights), or export -> broadcast -> import
+// between processes (bench.py --broadcast_weights: torch.distributed broadcast of the host blob, RCCL when the group is nccl).
+// Blob layout: magic, plan hash, nconv, wq_exp[nconv], arena bytes, arena, then per conv the Caffe-layout floats (so that
+// rtp_get_conv_weights / rtp_save_caffemodel of the receiver stay truthful).
+namespace {
+uint64_t plan_hash(const rtp_engine* e) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+  mix(e->weights_bytes); mix(e->convs.size()); mix((uint64_t)e->mode);
+  for (auto& c : e->convs) { mix(c.w_off); mix(c.b_off); mix(c.w_bytes); mix((uint64_t)c.cfg); mix((uint64_t)c.nchunk); mix((uint64_t)c.h8); for (char ch : c.name) mix((uint64_t)(unsigned char)ch); }
+  return h;
+}
+size_t ref_floats(const rtp_engine* e) {
+  size_t n = 0;
+  for (size_t i = 0; i < e->convs.size(); ++i) n += e->w_ref[i].size() + e->b_ref[i].size();
+  return n;
+}
+}  // namespace
+long rtp_weight_blob_bytes(const rtp_engine* e) {
+  if (!e) return RTP_EINVAL;
+  return (long)(4 * sizeof(uint64_t) + e->convs.size() * sizeof(int) + e->weights_bytes + ref_floats(e) * sizeof(float));
+}
+int rtp_weight_blob_export(rtp_engine* e, void* host, size_t capacity) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!host || (long)capacity < rtp_weight_blob_bytes(e)) return fail(e, RTP_EINVAL, "weight blob needs %ld bytes", rtp_weight_blob_bytes(e));
+  unsigned char* p = (unsigned char*)host;
+  const uint64_t head[4] = {0x5254505742303031ull /* "RTPWB001" */, plan_hash(e), (uint64_t)e->convs.size(), (uint64_t)e->weights_bytes};
+  memcpy(p, head, sizeof head); p += sizeof head;
+  for (auto& c : e->convs) { memcpy(p, &c.wq_exp, sizeof(int)); p += sizeof(int); }
+  HIPCHK(e, hipMemcpy(p, e->dweights, e->weights_bytes, hipMemcpyDeviceToHost)); p += e->weights_bytes;
+  for (size_t i = 0; i < e->convs.size(); ++i) {
+    memcpy(p, e->w_ref[i].data(), e->w_ref[i].size() * sizeof(float)); p += e->w_ref[i].size() * sizeof(float);
+    memcpy(p, e->b_ref[i].data(), e->b_ref[i].size() * sizeof(float)); p += e->b_ref[i].size() * sizeof(float);
+  }
+  return RTP_OK;
+}
+int rtp_weight_blob_import(rtp_engine* e, const void* host, size_t bytes) {
+  int rc;
+  if ((rc = need_idle(e))) return rc;
+  if (!host || (long)bytes < rtp_weight_blob_bytes(e)) return fail(e, RTP_EINVAL, "weight blob too short (%zu bytes, this plan needs %ld)", bytes, rtp_weight_blob_bytes(e));
+  const unsigned char* p = (const unsigned char*)host;
+  uint64_t head[4];
+  memcpy(head, p, sizeof head); p += sizeof head;
+  if (head[0] != 0x5254505742303031ull) return fail(e, RTP_EINVAL, "not a weight blob");
+  if (head[1] != plan_hash(e) || head[2] != e->convs.size() || head[3] != e->weights_bytes)
+    return fail(e, RTP_EINVAL, "weight blob was exported by an engine with another plan (model / resolution / precision / split set must match)");
+  bool moved = false;
+  for (auto& c : e->convs) { int ex; memcpy(&ex, p, sizeof(int)); p += sizeof(int); moved = moved || ex != c.wq_exp; c.wq_exp = ex; }
+  HIPCHK(e, hipDeviceSynchronize());
+  HIPCHK(e, hipMemcpy(e->dweights, p, e->weights_bytes, hipMemcpyHostToDevice)); p += e->weights_bytes;
+  for (size_t i = 0; i < e->convs.size(); ++i) {
+    memcpy(e->w_ref[i].data(), p, e->w_ref[i].size() * sizeof(float)); p += e->w_ref[i].size() * sizeof(float);
+    memcpy(e->b_ref[i].data(), p, e->b_ref[i].size() * sizeof(float)); p += e->b_ref[i].size() * sizeof(float);
+  }
+  if (moved && (rc = invalidate_graphs(e))) return rc;  // ConvParams::wq_exp is baked into the captured graphs
+  return RTP_OK;
+}
+// dst takes src's packed arena device-to-device (hipMemcpyPeer: xGMI between two GPUs of a node); both engines idle, same plan.
+int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src) {
+  if (!dst || !src) return RTP_EINVAL;
+  int rc;
+  if ((rc = need_idle(dst))) return rc;
+  if (!src->fifo.empty()) return fail(dst, RTP_EAGAIN, "rtp_copy_weights_from: the source engine has frames in flight");
+  if (plan_hash(dst) != plan_hash(src)) return fail(dst, RTP_EINVAL, "rtp_copy_weights_from: the engines have different plans");
+  HIPCHK(dst, hipDeviceSynchronize());
+  HIPCHK(dst, hipMemcpyPeer(dst->dweights, dst->cfg.device_id, src->dweights, src->cfg.device_id, dst->weights_bytes));
+  bool moved = false;
+  for (size_t i = 0; i < dst->convs.size(); ++i) {
+    moved = moved || dst->convs[i].wq_exp != src->convs[i].wq_exp;
+    dst->convs[i].wq_exp = src->convs[i].wq_exp;
+    dst->w_ref[i] = src->w_ref[i];
+    dst->b_ref[i] = src->b_ref[i];
+  }
+  if (moved && (rc = invalidate_graphs(dst))) return rc;
   return RTP_OK;
 }
 

@@ -2,6 +2,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Experiment knobs (tile overrides, ablation variants of the ring kernel — some of which compute WRONG results on purpose, stream
+// plans, diagnostic probes) exist only in the second build target librtpose_mi355x_exp.so (-DRTP_EXPERIMENTS, used by tools/):
+// in the production library the macro is a null pointer and the knob's name is not even a string in the binary
+// (tests/test_host_cpu.py greps for them).  The production library reads ONE environment variable: RTP_EXEC=eager|graph.
+#ifdef RTP_EXPERIMENTS
+#define RTP_EXP_ENV(name) getenv(name)
+#else
+#define RTP_EXP_ENV(name) ((const char*)nullptr)
+#endif
 
 namespace rtp {
 

@@ -1272,7 +1272,7 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
   ConnectParams pa = p;
   {
     const size_t extra = 8 + ((size_t)p.num_parts * 3 * (p.max_peaks + 1) + (size_t)p.num_limbs * p.max_peaks * 3 + p.num_limbs) * 4;
-    static const char* np = getenv("RTP_ASSEMBLE_PRELOAD");  // experiments: 0 = no LDS copy of the assembly inputs
+    static const char* np = RTP_EXP_ENV("RTP_ASSEMBLE_PRELOAD");  // experiments: 0 = no LDS copy of the assembly inputs
     pa.assemble_preload = (lds2 + extra <= 150 * 1024 && !(np && np[0] == '0')) ? 1 : 0;
     if (pa.assemble_preload) lds2 += extra;
   }
@@ -1295,7 +1295,7 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
   } else hipLaunchKernelGGL(connect_pairs_kernel<false>, dim3((cap + PAIRS_WG - 1) / PAIRS_WG, p.num_limbs), dim3(PAIRS_WG), 0, stream, p, ResizeParams{}, 0);
   e = hipGetLastError();
   if (e != hipSuccess || p.diag_stages == 1) return e;
-  static const char* mw = getenv("RTP_MATCH_WGS");  // experiments: workgroups of the match kernel (default: one per limb)
+  static const char* mw = RTP_EXP_ENV("RTP_MATCH_WGS");  // experiments: workgroups of the match kernel (default: one per limb)
   int match_wgs = mw ? atoi(mw) : p.num_limbs;
   if (match_wgs < 1 || match_wgs > p.num_limbs) match_wgs = p.num_limbs;
   hipLaunchKernelGGL(connect_match_kernel, dim3(match_wgs), dim3(256), lds1, stream, p);

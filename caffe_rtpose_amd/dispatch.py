@@ -59,3 +59,16 @@ def scaled_steps(steps, est_steps_per_s, min_seconds, dist=None):
 def aggregate_fps(steps_per_rank, world, seconds):
     """Whole-job throughput: every rank processed steps_per_rank frames (weak scaling)."""
     return steps_per_rank * world / seconds
+
+
+def broadcast_bytes(buf, src, dist, device="cpu"):
+    """One-time broadcast of a host byte blob (numpy uint8, same length on every rank) from rank `src`: the weight blob of
+    bench.py --broadcast_weights (the only collective this path can use, and not on the per-frame path).
+    With the nccl backend the bytes go host -> device -> RCCL broadcast over xGMI -> host; with gloo over TCP."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(buf, np.uint8))
+    if device != "cpu":
+        t = t.to(device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()

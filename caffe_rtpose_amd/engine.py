@@ -439,6 +439,63 @@ class Engine:
     def save_prototxt(self, path):
         self._chk(lib.rtp_save_prototxt(self.h, str(path).encode()))
 
+    # ---- load-time precision calibration
+    def calibrate_precision(self, frames=None, nframes=2, target=0.7e-3):
+        """rtp_calibrate_precision: returns (rules, err_before, err_after); frames = [n][N][3][H][W] float32 or None (synthetic)."""
+        buf = C.create_string_buffer(4096)
+        a, b = C.c_float(), C.c_float()
+        if frames is not None:
+            frames = np.ascontiguousarray(frames, np.float32)
+            nframes = frames.size // (self.N * 3 * self.net_h * self.net_w)
+        self._chk(lib.rtp_calibrate_precision(self.h, _f(frames) if frames is not None else None, int(nframes), float(target), buf, len(buf), C.byref(a), C.byref(b)))
+        return buf.value.decode(), a.value, b.value
+
+    def calibration_report(self):
+        return lib.rtp_calibration_report(self.h).decode()
+
+    def split_layers(self):
+        buf = C.create_string_buffer(4096)
+        p = C.c_int()
+        self._chk(lib.rtp_get_split_layers(self.h, buf, len(buf), C.byref(p)))
+        return buf.value.decode(), p.value
+
+    # ---- caller-owned device buffers (the engine's HIP runtime; bench.py keeps torch out of the data path)
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(lib.rtp_device_alloc(self.h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, dptr):
+        self._chk(lib.rtp_device_free(self.h, C.c_void_p(dptr)))
+
+    def device_upload(self, dptr, arr):
+        a = np.ascontiguousarray(arr)
+        self._chk(lib.rtp_device_upload(self.h, C.c_void_p(dptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def device_frame(self, x):
+        """A net input resident in HBM (for submit_device): allocates on the engine's device and uploads x."""
+        x = np.ascontiguousarray(x, np.float32)
+        p = self.device_alloc(x.nbytes)
+        self.device_upload(p, x)
+        return p
+
+    def synchronize(self):
+        self._chk(lib.rtp_device_synchronize(self.h))
+
+    # ---- one-time weight distribution between replicas
+    def weight_blob(self):
+        n = lib.rtp_weight_blob_bytes(self.h)
+        buf = np.empty(n, np.uint8)
+        self._chk(lib.rtp_weight_blob_export(self.h, buf.ctypes.data_as(C.c_void_p), n))
+        return buf
+
+    def load_weight_blob(self, buf):
+        b = np.ascontiguousarray(buf, np.uint8)
+        self._chk(lib.rtp_weight_blob_import(self.h, b.ctypes.data_as(C.c_void_p), b.nbytes))
+
+    def copy_weights_from(self, other):
+        self._chk(lib.rtp_copy_weights_from(self.h, other.h))
+
     # ---- diagnostics
     def last_stage_ms(self):
         ms = (C.c_float * 5)()

@@ -42,15 +42,19 @@ extern "C" {
 #define RTP_PREC_FP16 0 /* fp16 storage, MFMA f16 with fp32 accumulate: fastest, 2-2.6x OUTSIDE +-1e-3 */
 #define RTP_PREC_FP32 1 /* fp32 storage, exact-f32 MFMA (parity path, 1/16 the MFMA rate)   */
 #define RTP_PREC_MIXED 2 /* fp16 MFMA; the layers named by split_layers (default: the set whose fp16 rounding   *
-                          * dominates the final-map error) run SPLIT: activations and weights as hi + lo fp16   *
-                          * pairs, three MFMA passes a_hi*W_hi + a_lo*W_hi + a_hi*W_lo into one fp32            *
-                          * accumulator (~22 significant bits).  Reference arithmetic is fp32 throughout        *
-                          * (base_conv_layer.cpp:257-280); this is the mode that meets +-1e-3 on the maps.       */
+                          * dominates the final-map error) also multiply the rounding errors of both operands:  *
+                          * a_hi*W_hi + a_lo*W_hi + a_hi*W_lo into one fp32 accumulator.  On the 3x3 / 7x7      *
+                          * layers the two corrections are ONE extra K chunk of MX-scaled fp8 MFMA (2 pass-     *
+                          * times in all), on the 1x1 layers two more fp16 passes.  Reference arithmetic is     *
+                          * fp32 throughout (base_conv_layer.cpp:257-280); this is the fastest mode that meets  *
+                          * +-1e-3 on the maps.  rtp_calibrate_precision checks / widens the set on the loaded  *
+                          * weights.                                                                             */
 #define RTP_PREC_F16X3 3 /* every layer split: fp32-class accuracy at about 1/3 of the fp16 rate                 */
 
-#define RTP_EXEC_GRAPH 0 /* default: the static launch plan of one batch (conv stack + every frame's  *
-                          * post-processing chain + D2H) is captured ONCE per (engine, frames in the  *
-                          * batch) into a hipGraph and replayed with one hipGraphLaunch per batch      */
+#define RTP_EXEC_GRAPH 0 /* default: the conv stack of one batch (~50 launches) is captured ONCE per     *
+                          * (context, frames in the batch) into a hipGraph and replayed with one       *
+                          * hipGraphLaunch; each frame's short post-processing chain + D2H is launched  *
+                          * eagerly on the frame's own stream (rtp_collect waits for its frame only)    */
 #define RTP_EXEC_EAGER 1 /* one HIP launch per kernel (diagnostics; per-stage event timing)            */
 
 #define RTP_MAX_PEOPLE 96    /* RENDER_MAX_PEOPLE, include/rtpose/renderFunctions.h:6 */
@@ -89,9 +93,15 @@ typedef struct rtp_config {
                             * contains text, "@1x1" = every 1x1 layer, "@all"; ":w" splits only the  *
                             * weights, ":a" only the input activations, none = both.                  */
   int keep_blobs;          /* 0 (default): blobs that only feed a fused consumer are not written (the     *
-                            * convolutions in front of the three pooling layers pool in their epilogue).   *
-                            * 1: every blob of the graph stays tappable by rtp_get_blob (= blob_by_name),   *
-                            * pooling runs as its own launch; same values either way.                       */
+                            * convolutions in front of the three pooling layers pool in their epilogue):    *
+                            * rtp_get_blob("conv1_2" / "conv2_2" / "conv3_4") then returns RTP_EINVAL —      *
+                            * UNLIKE Net::blob_by_name, which has every blob.  1: every blob of the graph    *
+                            * stays tappable, pooling runs as its own launch; same values either way.        */
+  int calibrate_frames;    /* > 0 (RTP_PREC_MIXED only): rtp_engine_create ends with                         *
+                            * rtp_calibrate_precision(e, NULL, calibrate_frames, calibrate_target, ...) on    *
+                            * synthetic frames, i.e. the split set is checked — and widened if necessary —    *
+                            * on the weights that were just loaded (net.cpp:750-803).  0 = off.               */
+  float calibrate_target;  /* max |mixed - f16x3| / max |map| the calibration accepts (<= 0: 0.7e-3)         */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
@@ -205,6 +215,35 @@ int rtp_save_caffemodel(const rtp_engine* e, const char* path);
 /* Emit the engine's layer graph as deploy-prototxt text. */
 int rtp_save_prototxt(const rtp_engine* e, const char* path);
 
+/* Load-time precision calibration (where trained weights arrive: CopyTrainedLayersFrom, net.cpp:750-803).  The default
+ * split set of RTP_PREC_MIXED was chosen on synthetic weights; this measures it on the LOADED weights: nframes sample frames
+ * (frames_host: nframes x num_scales x 3 x net_h x net_w floats as rtp_submit takes them, or NULL = seeded synthetic frames)
+ * run through RTP_PREC_F16X3 (every layer split: 1e-5-class reference) and through the current mixed plan;
+ * err = max |mixed - f16x3| / max |f16x3| over the final maps.  While err > target (<= 0: 0.7e-3) the layer group whose
+ * promotion lowers the error most joins the split set and the engine is re-planned (arena, packed weights, graphs); if every
+ * group is in and the target is still missed the engine switches to RTP_PREC_F16X3.  rules_out (may be NULL) receives the
+ * final rule list ("@f16x3" after the fallback), err_before / err_after the measured errors.  Idle engine only; seconds. */
+int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes, float target, char* rules_out, size_t rules_len,
+                            float* err_before, float* err_after);
+const char* rtp_calibration_report(const rtp_engine* e); /* what the last calibration tried and chose, as text */
+int rtp_get_split_layers(const rtp_engine* e, char* buf, size_t buflen, int* precision);
+
+/* Caller-owned device buffers on the engine's device (replaces blobs()[0]->mutable_gpu_data() as a caller-filled H2D target,
+ * rtpose.cpp:1131): what rtp_submit_device reads.  Freed by rtp_device_free or with the engine. */
+int rtp_device_alloc(rtp_engine* e, size_t bytes, void** dptr);
+int rtp_device_free(rtp_engine* e, void* dptr);
+int rtp_device_upload(rtp_engine* e, void* dst_device, const void* src_host, size_t bytes);
+int rtp_device_synchronize(rtp_engine* e);
+
+/* One-time weight distribution between replicas (optional; the reference reads the .caffemodel once per GPU thread,
+ * rtpose.cpp:183-184).  Blob = the PACKED weight arena + the Caffe-layout floats of an idle engine; the receiver must have
+ * the same plan (model, resolution, batch, precision, split set).  rtp_copy_weights_from: device to device (hipMemcpyPeer,
+ * xGMI) between two engines of one process. */
+long rtp_weight_blob_bytes(const rtp_engine* e);
+int rtp_weight_blob_export(rtp_engine* e, void* host, size_t capacity);
+int rtp_weight_blob_import(rtp_engine* e, const void* host, size_t bytes);
+int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src);
+
 /* ---- host-side pieces of the path (no GPU needed) ---------------------------------------- */
 /* ModelDescriptor tables (modelDescriptorFactory.cpp:25-26,52-53). limb_seq/map_idx: 2*num_limbs ints. */
 int rtp_model_tables(int model, int* num_parts, int* num_limbs, int* limb_seq, int* map_idx);
@@ -278,8 +317,8 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
  * Call with an idle engine to harvest.  (Round 2 compared wall-clock stamps of workgroups on different
  * XCDs; their clocks are not synchronised on every box.) */
 int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch);
-/* The same totals split by the number of MFMA passes of the launch (1 = plain fp16 layer, 3 = split-precision layer);
- * index 0 is unused. */
+/* The same totals split by the MFMA pass-times of the launch: 1 = plain fp16 layer, 2 = fp16 + one fp8 error-compensation
+ * chunk per channel group (RTP_PREC_MIXED on 3x3 / 7x7 layers), 3 = three fp16 passes (RTP_PREC_F16X3); index 0 is unused. */
 int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches[4]);
 /* Host float -> OCP e4m3 (round to nearest even, clamped to +-448): how the fp8 weight copies of split layers are made. */
 int rtp_debug_f32_to_e4m3(const float* in, unsigned char* out, int n);

@@ -369,8 +369,20 @@ struct OrcConnectParams {
 // (rtpose.cpp:584,611 / :843,897) and so reads other parts' slots — or past the blob — when a
 // part has more than max_peaks peaks.  That is out-of-contract for the reference (undefined
 // for the last parts).  The oracle, and the engine with it, clamp nA/nB to max_peaks here.
+// Optional decision trace (tests/_explain.py, bench.py's `parity`): every PAF test, every greedy pick and every subset row is
+// recorded NEXT TO the arithmetic above/below, which it does not touch (orc_connect == orc_connect_trace in every output).
+struct OrcConnectTrace {
+  // cand rows: limb, i, j, accepted (count > inter_min_above), sum / count (0 when count == 0), count,
+  //            thr_margin = how far the sample that would have to cross inter_threshold to flip `accepted` is from it,
+  //            round_margin = smallest distance of a sample coordinate to the .5 where roundf() switches pixels, norm_vec,
+  //            near_thr = smallest |sample - inter_threshold| over the 10 samples (a count change inside an accepted pair)
+  std::vector<double> cand;
+  std::vector<double> conn;  // limb, i, j, score — in pick order
+  std::vector<double> rows;  // num_parts entries (peaks offsets, 0 = absent), count, score, kept (0/1)
+};
+
 static int orc_connect_impl(bool coco, const float* heatmap_pointer, const float* peaks, int max_peaks,
-                            float* joints, const OrcConnectParams& P) {
+                            float* joints, const OrcConnectParams& P, OrcConnectTrace* T = nullptr) {
   const int num_parts = coco ? 18 : 15;
   const int number_limb_seq = coco ? 19 : 14;
   const int* limbSeq = coco ? COCO_LIMB : MPI_LIMB;
@@ -449,7 +461,13 @@ static int orc_connect_impl(bool coco, const float* heatmap_pointer, const float
         const float vec_y = d_y / norm_vec;
         float sum = 0;
         int count = 0;
+        float t_scores[10];
+        double t_round = 1.0;
         for (int lm = 0; lm < num_inter; lm++) {
+          if (T) {
+            const float cy = s_y + lm * d_y / num_inter, cx = s_x + lm * d_x / num_inter;
+            t_round = std::min(t_round, std::min(std::fabs((double)cy - std::floor((double)cy) - 0.5), std::fabs((double)cx - std::floor((double)cx) - 0.5)));
+          }
           int my = (int)roundf(s_y + lm * d_y / num_inter);
           int mx = (int)roundf(s_x + lm * d_x / num_inter);
           if (coco) {  // rtpose.cpp:920-929 (MPI has no clamp: :630-632)
@@ -460,10 +478,27 @@ static int orc_connect_impl(bool coco, const float* heatmap_pointer, const float
           if (mx < 0 || my < 0 || (!coco && (mx >= NW || my >= NH))) return -2;
           const int idx = my * NW + mx;
           const float score = (vec_x * map_x[idx] + vec_y * map_y[idx]);
+          t_scores[lm] = score;
           if (score > P.inter_threshold) {
             sum = sum + score;
             count++;
           }
+        }
+        if (T) {
+          const bool acc = count > P.inter_min_above_threshold;
+          // samples on the side that would have to cross the threshold, nearest first; `need` of them must cross
+          std::vector<double> dist;
+          for (int lm = 0; lm < num_inter; lm++) {
+            const bool above = t_scores[lm] > P.inter_threshold;
+            if (above == acc) dist.push_back(std::fabs((double)t_scores[lm] - (double)P.inter_threshold));
+          }
+          std::sort(dist.begin(), dist.end());
+          const int need = acc ? count - P.inter_min_above_threshold : P.inter_min_above_threshold + 1 - count;
+          const double thr_margin = (need >= 1 && need <= (int)dist.size()) ? dist[need - 1] : 1e30;
+          double near_thr = 1e30;
+          for (int lm = 0; lm < num_inter; lm++) near_thr = std::min(near_thr, std::fabs((double)t_scores[lm] - (double)P.inter_threshold));
+          const double row[10] = {(double)k, (double)i, (double)j, acc ? 1.0 : 0.0, count ? (double)(sum / count) : 0.0, (double)count, thr_margin, t_round, (double)norm_vec, near_thr};
+          T->cand.insert(T->cand.end(), row, row + 10);
         }
         if (count > P.inter_min_above_threshold) {
           std::vector<double> row_vec(4, 0);
@@ -491,6 +526,7 @@ static int orc_connect_impl(bool coco, const float* heatmap_pointer, const float
         row_vec[1] = limbSeq[2 * k + 1] * peaks_offset + j * 3 + 2;
         row_vec[2] = score;
         connection_k.push_back(row_vec);
+        if (T) { const double row[4] = {(double)k, (double)i, (double)j, (double)score}; T->conn.insert(T->conn.end(), row, row + 4); }
         cnt = cnt + 1;
         occurA[i - 1] = 1;
         occurB[j - 1] = 1;
@@ -534,6 +570,13 @@ static int orc_connect_impl(bool coco, const float* heatmap_pointer, const float
     }
   }
 
+  if (T)
+    for (size_t i = 0; i < subset.size(); i++) {
+      for (int j = 0; j < num_parts; j++) T->rows.push_back(subset[i][j]);
+      T->rows.push_back(subset[i][SUBSET_CNT]);
+      T->rows.push_back(subset[i][SUBSET_SCORE]);
+      T->rows.push_back((subset[i][SUBSET_CNT] >= P.min_subset_cnt && (subset[i][SUBSET_SCORE] / subset[i][SUBSET_CNT]) > P.min_subset_score) ? 1.0 : 0.0);
+    }
   int cnt = 0;
   for (size_t i = 0; i < subset.size(); i++) {
     if (subset[i][SUBSET_CNT] >= P.min_subset_cnt && (subset[i][SUBSET_SCORE] / subset[i][SUBSET_CNT]) > P.min_subset_score) {
@@ -563,6 +606,22 @@ ORC_API int orc_connect(int model, const float* heatmap, const float* peaks, int
                         int min_subset_cnt, float min_subset_score, int max_people, float* joints) {
   OrcConnectParams P{net_w, net_h, disp_w, disp_h, inter_threshold, inter_min_above, min_subset_cnt, min_subset_score, max_people};
   return orc_connect_impl(model == 0, heatmap, peaks, max_peaks, joints, P);
+}
+
+// orc_connect + its decision trace.  cand [cap][10], conn [cap][4], rows [cap][num_parts + 3]; n_* receive the row counts
+// (rows beyond a cap are dropped, the count still says how many there were).
+ORC_API int orc_connect_trace(int model, const float* heatmap, const float* peaks, int max_peaks, int net_w, int net_h, int disp_w, int disp_h,
+                              float inter_threshold, int inter_min_above, int min_subset_cnt, float min_subset_score, int max_people, float* joints,
+                              double* cand, long cand_cap, long* n_cand, double* conn, long conn_cap, long* n_conn, double* rows, long rows_cap, long* n_rows) {
+  OrcConnectParams P{net_w, net_h, disp_w, disp_h, inter_threshold, inter_min_above, min_subset_cnt, min_subset_score, max_people};
+  OrcConnectTrace T;
+  const int n = orc_connect_impl(model == 0, heatmap, peaks, max_peaks, joints, P, &T);
+  const int rw = (model == 0 ? 18 : 15) + 3;
+  *n_cand = (long)T.cand.size() / 10; *n_conn = (long)T.conn.size() / 4; *n_rows = (long)T.rows.size() / rw;
+  memcpy(cand, T.cand.data(), sizeof(double) * 10 * std::min(*n_cand, cand_cap));
+  memcpy(conn, T.conn.data(), sizeof(double) * 4 * std::min(*n_conn, conn_cap));
+  memcpy(rows, T.rows.data(), sizeof(double) * rw * std::min(*n_rows, rows_cap));
+  return n;
 }
 
 // Default thresholds (rtpose.cpp:212-226).

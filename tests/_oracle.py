@@ -112,6 +112,33 @@ def connect(model, resized, peaks, max_peaks, net_w, net_h, disp_w, disp_h, thr=
     return cnt, joints
 
 
+def connect_trace(model, resized, peaks, max_peaks, net_w, net_h, disp_w, disp_h, thr=None, max_people=96):
+    """connect() plus the decision trace of the same run: (count, joints, cand, conn, rows) with
+    cand [n][10] = limb, i, j, accepted, sum/count, count, thr_margin, round_margin, norm_vec, near_thr  (EVERY peak pair of every limb),
+    conn [n][4]  = limb, i, j, score  (greedy picks in pick order),
+    rows [n][num_parts + 3] = subset rows: peaks offsets per part (0 = absent), count, score, kept."""
+    thr = thr or default_thresholds(model)
+    num_parts = 18 if model == 0 else 15
+    r = np.ascontiguousarray(resized, np.float32)
+    p = np.ascontiguousarray(peaks, np.float32)
+    joints = np.zeros((max_people, num_parts, 3), np.float32)
+    nl = 19 if model == 0 else 14
+    cap_c, cap_k, cap_r = nl * max_peaks * max_peaks, nl * max_peaks, 2 * nl * max_peaks
+    cand = np.zeros((cap_c, 10), np.float64)
+    conn = np.zeros((cap_k, 4), np.float64)
+    rows = np.zeros((cap_r, num_parts + 3), np.float64)
+    nc, nk, nr = C.c_long(), C.c_long(), C.c_long()
+    dp = C.POINTER(C.c_double)
+    cnt = lib().orc_connect_trace(model, _f(r), _f(p), max_peaks, net_w, net_h, disp_w, disp_h,
+                                  C.c_float(thr["inter_threshold"]), thr["inter_min_above"], thr["min_subset_cnt"],
+                                  C.c_float(thr["min_subset_score"]), max_people, _f(joints),
+                                  cand.ctypes.data_as(dp), C.c_long(cap_c), C.byref(nc), conn.ctypes.data_as(dp), C.c_long(cap_k), C.byref(nk),
+                                  rows.ctypes.data_as(dp), C.c_long(cap_r), C.byref(nr))
+    assert cnt >= 0, f"oracle connect failed {cnt}"
+    assert nc.value <= cap_c and nk.value <= cap_k and nr.value <= cap_r
+    return cnt, joints, cand[:nc.value], conn[:nk.value], rows[:nr.value]
+
+
 def render_pose(model, bgr, joints, num_people, googly=0):
     img = np.ascontiguousarray(bgr, np.uint8)
     j = np.ascontiguousarray(joints, np.float32).reshape(-1)

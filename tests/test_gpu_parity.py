@@ -96,7 +96,10 @@ def test_pooling_fused_into_the_convolution_epilogue_is_bit_identical(prec, mode
     ek = _engine(keep_blobs=1, **kw)
     plan = r.plan_summary(ef.cfg)
     nf = plan.count("+pool")   # small resolutions put some trunk layers on tiles without a pooled variant: those keep their pooling launch
-    assert nf >= (3 if W >= 640 else 2 if W >= 480 else 1 if W >= 320 else 0)  # fusion needs 128-pixel tiles and >= 128 columns at that level and nf + plan.count("step pool") == 3 and r.plan_summary(ek.cfg).count("step pool") == 3
+    # fusion needs 128-pixel tiles and >= 128 columns at that level
+    assert nf >= (3 if W >= 640 else 2 if W >= 480 else 1 if W >= 320 else 0)
+    # a layer that is not fused keeps its stand-alone pooling launch; keep_blobs = 1 restores all three
+    assert nf + plan.count("step pool") == 3 and r.plan_summary(ek.cfg).count("step pool") == 3
     fused_away = [ln.split()[2] for ln in plan.splitlines() if "+pool" in ln]
     def tiles(pl):   # (layer, tile, chunk bytes) of every convolution launch: the two plans must run the same kernels to be comparable bit for bit
         return [(w[2], w[w.index("tile") + 1], w[w.index("rowb") + 1]) for w in (ln.replace(" +pool", "").split() for ln in pl.splitlines() if ln.startswith("step conv"))]
@@ -692,7 +695,8 @@ def test_device_preprocess_equals_independent_opencv_restatement(geom):
 def test_ring_kernel_variants_are_bit_identical():
     """RTP_RING_ILV=1 (interleaved A-fragment rows: DPP shifts instead of LDS re-reads, conv_ring.hip) and RTP_HALO_SHARED=0 (a
     halo on both sides of every row) only change HOW operands reach the MFMAs: low-res maps, blobs and joints hash identically
-    to the default build (tools/ab_hash.py, separate processes: the switches are read once per process)."""
+    to the default build (tools/ab_hash.py, separate processes: the switches are read once per process).  The knobs exist in the
+    EXPERIMENTS build only (librtpose_mi355x_exp.so, selected by RTP_LIB); the production library ignores them — checked too."""
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ab_hash.py")
@@ -704,7 +708,12 @@ def test_ring_kernel_variants_are_bit_identical():
         assert out.returncode == 0, out.stderr[-2000:]
         return [l for l in out.stdout.splitlines() if l and not l.startswith("#")]
 
+    exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "caffe_rtpose_amd", "librtpose_mi355x_exp.so")
+    assert os.path.exists(exp), "build the experiments library (make -C caffe_rtpose_amd/csrc)"
+    strip = lambda lines: [l.split(" RTP_")[0] if " RTP_" in l else l for l in lines]   # (ab_hash prints the RTP_* environment as a tag)
     base = run()
     assert len(base) == 2 and all("nan 0" in l for l in base)
-    assert run(RTP_RING_ILV="1") == base
-    assert run(RTP_HALO_SHARED="0") == base
+    assert strip(run(RTP_LIB=exp)) == strip(base)                                # the experiments build without knobs = the production bits
+    assert strip(run(RTP_LIB=exp, RTP_RING_ILV="1")) == strip(base)
+    assert strip(run(RTP_LIB=exp, RTP_HALO_SHARED="0")) == strip(base)
+    assert strip(run(RTP_RING_VAR="12", RTP_DIAG_SKIP_POST="2")) == strip(base)  # the production library does not know these names
