@@ -117,6 +117,7 @@ SIGNATURES = {
     "rtp_weight_blob_export": (C.c_int, [vp, vp, C.c_size_t]),
     "rtp_weight_blob_import": (C.c_int, [vp, vp, C.c_size_t]),
     "rtp_copy_weights_from": (C.c_int, [vp, vp]),
+    "rtp_device_local_cpus": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

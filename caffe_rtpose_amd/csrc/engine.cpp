@@ -2583,6 +2583,26 @@ int rtp_device_synchronize(rtp_engine* e) {
   return RTP_OK;
 }
 
+// The CPUs next to a device (its PCI function's local_cpulist in sysfs, e.g. "0-31,128-159"): rtpose.bin pins worker g's thread there so
+// that the pinned staging buffers it allocates and fills (rtp_submit_frame's copy of the 2.76 MB frame) live on the GPU's NUMA node.
+// Returns the length written, 0 when the topology is not exposed (containers), or a negative code.
+int rtp_device_local_cpus(int device_id, char* buf, size_t buflen) {
+  if (!buf || buflen < 2) return RTP_EINVAL;
+  buf[0] = 0;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof bus, device_id) != hipSuccess) return RTP_ENODEV;
+  for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+  std::ifstream f(path);
+  if (!f) return 0;
+  std::string line;
+  std::getline(f, line);
+  while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back();
+  if (line.size() + 1 > buflen) return RTP_ERANGE;
+  memcpy(buf, line.c_str(), line.size() + 1);
+  return (int)line.size();
+}
+
 // ---- load-time precision calibration ----------------------------------------------------------------
 // The default split set of RTP_PREC_MIXED was chosen on one synthetic weight set.  Trained weights arrive through
 // CopyTrainedLayersFrom (net.cpp:750-803) with another spectrum; this measures the set on the weights that are LOADED:

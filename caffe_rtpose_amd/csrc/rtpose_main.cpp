@@ -21,6 +21,8 @@
 #include <future>
 #include <map>
 #include <mutex>
+#include <pthread.h>
+#include <sched.h>
 #include <queue>
 #include <string>
 #include <sys/stat.h>
@@ -62,6 +64,11 @@ struct Flags {
   double dry_engine = 0;
   int dry_people = 5;
   int producer_threads = 0;      // frames are generated / decoded ahead by this many threads (0 = hardware threads / 4, clamped to [2, 16])
+  bool share_weights = false;    // workers 1.. take worker 0's PACKED weight arena device to device (rtp_copy_weights_from: hipMemcpyPeer over xGMI)
+                                 // instead of keeping the copy they packed themselves (the reference: one .caffemodel read per GPU thread, rtpose.cpp:183-184)
+  bool pin_workers = true;       // every worker thread runs on the CPUs local to its GPU (rtp_device_local_cpus), so the pinned staging buffers it
+                                 // allocates and fills are on that NUMA node; --nopin_workers leaves the placement to the scheduler
+  int calibrate = 0;             // K > 0: rtp_calibrate_precision on K frames right after the weights are loaded (mixed precision only)
   int json_writers = -1;         // JSON files are written by this many threads (0 = by the display/writer thread itself, like the reference;
                                  // default: 1 thread per worker — creating a file costs the one display thread ~0.5 ms, 1600 frames/s at most)
 };
@@ -72,10 +79,10 @@ int parse_flags(int argc, char** argv, Flags& F) {
       {"net_resolution", &F.net_resolution}, {"camera_resolution", &F.camera_resolution}, {"precision", &F.precision}, {"model", &F.model}, {"devices", &F.devices}};
   std::map<std::string, int*> iflags = {{"part_to_show", &F.part_to_show}, {"camera", &F.camera}, {"start_frame", &F.start_frame},
       {"start_device", &F.start_device}, {"num_gpu", &F.num_gpu}, {"num_scales", &F.num_scales}, {"frames_in_flight", &F.frames_in_flight}, {"batch_frames", &F.batch_frames},
-      {"test_worker_delay_ms", &F.test_worker_delay_ms}, {"dry_people", &F.dry_people}, {"json_writers", &F.json_writers}, {"producer_threads", &F.producer_threads}};
+      {"test_worker_delay_ms", &F.test_worker_delay_ms}, {"dry_people", &F.dry_people}, {"json_writers", &F.json_writers}, {"producer_threads", &F.producer_threads}, {"calibrate", &F.calibrate}};
   std::map<std::string, double*> dflags = {{"start_scale", &F.start_scale}, {"scale_gap", &F.scale_gap}, {"dry_engine", &F.dry_engine}};
   std::map<std::string, bool*> bflags = {{"fullscreen", &F.fullscreen}, {"no_frame_drops", &F.no_frame_drops}, {"host_preprocess", &F.host_preprocess}, {"no_display", &F.no_display},
-      {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}};
+      {"no_text", &F.no_text}, {"logtostderr", &F.logtostderr}, {"share_weights", &F.share_weights}, {"pin_workers", &F.pin_workers}};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--help" || a == "-help" || a == "-h") return 2;
@@ -116,7 +123,9 @@ void usage() {
          "  --no_display --no_text --fullscreen --part_to_show N --logtostderr   [--precision mixed|fp16|f16x3|fp32 --frames_in_flight K --batch_frames B --host_preprocess\n"
          "   --devices d0,d1,.. (device of each worker; the same device may appear twice)\n"
          "   --dry_engine RATE (no GPU: every worker is a stand-in finishing RATE frames/s; measures the host side of --num_gpu N) --dry_people P\n"
-         "   --json_writers K (JSON files written by K threads instead of the one display thread) --producer_threads K (decode / generate ahead)]\n"
+         "   --json_writers K (JSON files written by K threads instead of the one display thread) --producer_threads K (decode / generate ahead)\n"
+         "   --calibrate K (check / widen the mixed-precision split set on the loaded weights with K sample frames)\n"
+         "   --share_weights (workers 1.. copy worker 0's packed weights GPU to GPU) --nopin_workers (no CPU affinity next to each worker's GPU)]\n"
          "  --write_frames draws the pose overlay only: the FPS / people-count text of the reference (cv::putText, rtpose.cpp:1319-1333) is not\n"
          "  drawn, i.e. --no_text is implied.\n");
 }
@@ -163,6 +172,8 @@ struct Global {
   std::atomic<bool> quit_threads{false};
   std::atomic<int> produced{0}, finished{0}, dropped{0};
   std::vector<int> per_worker;  // frames each worker submitted (dynamic pull from the one shared queue)
+  std::atomic<rtp_engine*> engine0{nullptr};  // --share_weights: worker 0's engine once it is up (idle until every worker is ready)
+  std::atomic<int> weights_shared{0};
   std::atomic<int> workers_ready{0};  // workers start pulling once EVERY engine is up (engine creation takes seconds, short inputs milliseconds)
   std::atomic<bool> producer_done{false};
   double first_commit = 0;                     // steady-state window: first frame committed .. last file written
@@ -297,6 +308,26 @@ void producer() {
   G.producer_done = true;
 }
 
+// CPU affinity of a worker thread: the CPUs local to its GPU's PCI function ("0-31,128-159"); silently skipped where sysfs does not say
+void pin_thread_near_device(int widx, int device) {
+  char list[512];
+  if (rtp_device_local_cpus(device, list, sizeof list) <= 0) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n = 0;
+  for (const char* p = list; *p;) {
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); ++n; }
+    if (*p == ',') ++p;
+  }
+  if (n > 0 && pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0) fprintf(stderr, "worker %d (GPU %d) runs on CPUs %s\n", widx, device, list);
+}
+
 // ---- per-GPU worker (processFrame, rtpose.cpp:1079-1203) -----------------------------------------
 void worker(int widx, int device, int* status) {
   rtp_config cfg;
@@ -312,13 +343,29 @@ void worker(int widx, int device, int* status) {
   cfg.frames_in_flight = F.frames_in_flight;
   cfg.batch_frames = F.batch_frames;
   cfg.render = F.write_frames.empty() ? 0 : 1 + F.part_to_show;  // render() of rtpose.cpp:270-299: pose overlay or a --part_to_show view
+  cfg.calibrate_frames = F.calibrate;
   rtp_engine* e = nullptr;
   const bool dry = F.dry_engine > 0;
+  if (!dry && F.pin_workers && F.num_gpu > 1) pin_thread_near_device(widx, device);
   if (!dry && rtp_engine_create(&cfg, &e) != RTP_OK) {
     fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));
     *status = 1;
     G.quit_threads = true;
     return;
+  }
+  if (!dry && F.share_weights) {  // worker 0 publishes its engine; the others take its packed arena before anybody submits a frame
+    if (widx == 0) G.engine0 = e;
+    else {
+      while (!G.engine0.load() && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      if (G.engine0.load() && rtp_copy_weights_from(e, G.engine0.load()) != RTP_OK) {
+        fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(e));
+        *status = 1;
+        G.quit_threads = true;
+        rtp_engine_destroy(e);
+        return;
+      }
+      G.weights_shared++;
+    }
   }
   int num_parts = F.model == "mpi" ? 15 : 18;
   if (!dry) rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
@@ -634,6 +681,7 @@ int main(int argc, char** argv) {
   for (int s : status) rc |= s;
   const double dt = wall() - t0;
   for (int g = 0; g < F.num_gpu; ++g) fprintf(stderr, "worker %d (GPU %d) processed %d frames\n", g, devs[g], G.per_worker[g]);
+  if (F.share_weights) fprintf(stderr, "share_weights: %d worker(s) took worker 0's packed weights\n", G.weights_shared.load());
   const double steady = (G.finished.load() > 1 && G.last_written.load() > G.first_commit) ? G.finished.load() / (G.last_written.load() - G.first_commit) : 0.0;
   fprintf(stderr, "rtcpm %s. Total time: %.3f seconds. frames produced %d, written %d, dropped %d (%.1f FPS incl. init, %.1f FPS first frame committed -> last frame written)\n",
           rc ? "FAILED" : "successfully finished", dt, G.produced.load(), G.finished.load(), G.dropped.load(), G.finished.load() / dt, steady);

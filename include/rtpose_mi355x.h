@@ -235,6 +235,10 @@ int rtp_device_free(rtp_engine* e, void* dptr);
 int rtp_device_upload(rtp_engine* e, void* dst_device, const void* src_host, size_t bytes);
 int rtp_device_synchronize(rtp_engine* e);
 
+/* The CPUs local to a device ("0-31,128-159": sysfs local_cpulist of its PCI function) for the worker thread that feeds it; returns
+ * the string length, 0 when the platform does not expose it. */
+int rtp_device_local_cpus(int device_id, char* buf, size_t buflen);
+
 /* One-time weight distribution between replicas (optional; the reference reads the .caffemodel once per GPU thread,
  * rtpose.cpp:183-184).  Blob = the PACKED weight arena + the Caffe-layout floats of an idle engine; the receiver must have
  * the same plan (model, resolution, batch, precision, split set).  rtp_copy_weights_from: device to device (hipMemcpyPeer,

@@ -29,11 +29,15 @@ cut_range "$IM" 8 18 '^template <typename Dtype>' '^}' imresize_8_18.inc
 cut_range "$IM" 98 155 '^template <typename Dtype>' '^}' imresize_98_155.inc
 cut_range "$NM" 14 113 '^template <typename Dtype>' '^}' nms_14_113.inc
 cut_range "$RF" 4 329 '^#define numThreadsPerBlock_1d 32' '^}' render_4_329.inc       # macros, colour maps, MPI kernels
+cut_range "$REF/src/caffe/util/im2col.cpp" 14 55 '^inline bool is_a_ge_zero_and_a_lt_b' '^}' im2col_14_55.inc
+cut_range "$REF/src/caffe/test/test_convolution_layer.cpp" 21 139 '^template <typename Dtype>' '^}' caffe_conv_21_139.inc
+cut_range "$REF/src/caffe/layers/pooling_layer.cpp" 90 107 'pooled_height_ = static_cast<int>' '^      pooled_width_\);' pooling_90_107.inc
+cut_range "$REF/src/caffe/layers/pooling_layer.cpp" 149 186 'caffe_set\(top_count, Dtype\(-FLT_MAX\), top_data\)' '^    }' pooling_149_186.inc
 cut_range "$RF" 394 975 '^__global__ void render_pose_coco_parts' '^}' render_394_975.inc  # COCO kernels (pose, heat maps, PAFs)
 
 CXX="${CXX:-g++}"
 # -ffp-contract=off and no -ffast-math: the floating point of the C++ source, nothing else
 FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -fno-fast-math -w -I$HERE -I$OUT -I$REF/include"
-$CXX $FLAGS -shared -o "$OUT/libref.so" "$HERE/ref_shim.cpp" "$REF/src/rtpose/modelDescriptor.cpp" "$REF/src/rtpose/modelDescriptorFactory.cpp"
+$CXX $FLAGS -shared -o "$OUT/libref.so" "$HERE/ref_shim.cpp" "$HERE/ref_conv_shim.cpp" "$REF/src/rtpose/modelDescriptor.cpp" "$REF/src/rtpose/modelDescriptorFactory.cpp"
 rm -rf "$OUT/gen"
 echo "built $OUT/libref.so"

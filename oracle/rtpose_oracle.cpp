@@ -20,10 +20,16 @@
 //   json      examples/rtpose/rtpose.cpp:1383-1416
 //
 // Parity pinning status:
-//   conv / pool / relu / concat : PINNED against the reference's own known-answer tests
-//       (src/caffe/test/test_pooling_layer.cpp:49-103, test_convolution_layer.cpp:21-139,
-//        :498-589, test_neuron_layer.cpp:208-221, test_concat_layer.cpp:143-167) — restated
-//       in tests/test_oracle_kat.py — and cross-checked against torch CPU conv2d.
+//   conv / pool : PINNED on the reference's OWN CODE: oracle/ref_recipe/build_ref.sh also cuts caffe_conv (the naive loop the
+//       reference's convolution tests trust, src/caffe/test/test_convolution_layer.cpp:21-139), im2col_cpu (src/caffe/util/
+//       im2col.cpp:14-55) and the MAX branch of PoolingLayer::Forward_cpu with Reshape's output size (src/caffe/layers/
+//       pooling_layer.cpp:90-107, 149-186) into oracle/_ref/libref.so behind a 90-line Blob / ConvolutionParameter stub;
+//       tests/test_ref_pin.py: orc_conv2d == caffe_conv within the reference tests' own 1e-4 and == im2col_cpu + GEMM within 2e-5 on
+//       the gtest shapes and on the linevec layer kinds (3->64 k3, 185->128 k7, 128->38 k1); orc_maxpool == the pooling loop bit for
+//       bit (even, odd / ceil-mode, padded).  Outputs travel in tests/golden/ref_pin.npz.  Not from the reference: the sgemm behind
+//       forward_cpu_gemm (cblas; no BLAS here) — a plain loop over the reference's im2col buffer stands in.
+//   relu / concat : the reference's known-answer tests restated (test_neuron_layer.cpp:208-221, test_concat_layer.cpp:143-167,
+//       tests/test_oracle_kat.py), cross-checked against torch CPU.
 //   imresize / nms / connect / json / prep / tables : PINNED on the reference's OWN CODE:
 //       oracle/ref_recipe/build_ref.sh cuts connectLimbs, connectLimbsCOCO, process_and_pad_image,
 //       ColumnCompare and the --write_json block out of examples/rtpose/rtpose.cpp, and
@@ -36,7 +42,8 @@
 //       reference's outputs to the GPU box (tools/make_ref_golden.py).
 //       Not reproduced by a host build: nvcc's default FMA contraction in the two kernels (the
 //       pinned semantics are those of the C++ source, -ffp-contract=off).
-//   The conv STACK as a whole (Caffe's Net + BLAS) cannot be built here; it rests on the KATs above.
+//   The conv STACK as a whole (Caffe's Net + BLAS + protobuf + glog) cannot be built here; it rests on the per-layer pins above
+//   and on the graph fixture (tests/golden/linevec_layers.json, from the reference's prototxt files).
 //
 // Build: see oracle/Makefile  (g++ -O2 -fopenmp -ffp-contract=off: source-level float
 // semantics, no FMA contraction, so every float op below rounds exactly where the

@@ -152,3 +152,29 @@ def view_cases(tables):
         maps = orc.imresize(np.ascontiguousarray(low, np.float32), net_w, net_h, 1.0, 0.3)[0]
         out.append((name, model, img, maps, parts))
     return out
+
+
+def conv_cases():
+    """(name, x [N][Cin][H][W], w [Cout][Cin][k][k], b or None, pad, stride): the shapes of the reference's own convolution tests
+    (test_convolution_layer.cpp:151-166, 231-265 TestSimpleConvolution: 2x3x6x4 bottom, 4 outputs, 3x3 stride 2; :443-468 1x1) and the
+    three kinds of layers on the linevec path at reduced spatial size where the naive loop would take minutes: the input convolution
+    (3 -> 64, k 3), a stage-entry 7x7 over the 185-channel concat, a branch-final 1x1 (128 -> 38) at the full 46x82 low-res size."""
+    rs = np.random.RandomState(1701)
+    g = lambda *s: rs.randn(*s).astype(np.float32)
+    yield "gtest_simple_k3_s2", g(2, 3, 6, 4), g(4, 3, 3, 3), np.full(4, 0.1, np.float32), 0, 2
+    yield "gtest_1x1", g(2, 3, 6, 4), g(4, 3, 1, 1), np.full(4, 0.1, np.float32), 0, 1
+    yield "gtest_no_bias_pad1", g(1, 2, 5, 7), g(3, 2, 3, 3), None, 1, 1
+    yield "conv1_1_3_64_k3", (rs.randint(0, 256, (2, 3, 16, 24)) / 256.0 - 0.5).astype(np.float32), (g(64, 3, 3, 3) * np.float32(np.sqrt(2 / 27))), rs.uniform(-0.1, 0.1, 64).astype(np.float32), 1, 1
+    yield "Mconv1_185_128_k7", np.maximum(g(1, 185, 8, 10), 0), g(128, 185, 7, 7) * np.float32(np.sqrt(2 / (185 * 49))), rs.uniform(-0.1, 0.1, 128).astype(np.float32), 3, 1
+    yield "Mconv7_128_38_k1", np.maximum(g(1, 128, 46, 82), 0), g(38, 128, 1, 1) * np.float32(np.sqrt(2 / 128)), rs.uniform(-0.1, 0.1, 38).astype(np.float32), 0, 1
+
+
+def pool_cases():
+    """(name, x, k, stride, pad): TestForwardSquare's plane (test_pooling_layer.cpp:49-103), the 2x2 / stride 2 pooling of the linevec
+    trunk on even and on odd sizes (ceil mode keeps the partial window), a padded case (the clip of pooling_layer.cpp:94-105)."""
+    rs = np.random.RandomState(7)
+    plane = np.array([[1, 2, 5, 2, 3], [9, 4, 1, 4, 8], [1, 2, 5, 2, 3]], np.float32)
+    yield "gtest_square_k2_s1", np.tile(plane, (2, 2, 1, 1)).astype(np.float32), 2, 1, 0
+    yield "linevec_64ch_even", rs.randn(2, 64, 32, 48).astype(np.float32), 2, 2, 0
+    yield "odd_5x7_ceil", rs.randn(1, 3, 5, 7).astype(np.float32), 2, 2, 0
+    yield "k3_s2_pad1", rs.randn(1, 2, 9, 10).astype(np.float32), 3, 2, 1

@@ -104,3 +104,48 @@ def write_json(tmpdir, joints, num_people, model, frame_scale, frame_number=7, i
     else:
         name = f"frame{frame_number:06d}.json"
     return name, open(os.path.join(str(tmpdir), name), "rb").read()
+
+
+# ---- the reference's own convolution / pooling code (oracle/ref_recipe/ref_conv_shim.cpp) ---------------------------------------
+def _conv_call(fn, x, w, b, pad, stride):
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    N, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = np.full((N, Cout, Ho, Wo), np.nan, np.float32)
+    rc = fn(_f(x), N, Cin, H, W, _f(w), _f(np.ascontiguousarray(b, np.float32)) if b is not None else None, Cout, kh, kw, pad, pad, stride, stride, _f(out))
+    if rc < 0:
+        lib().ref_conv_last_error.restype = C.c_char_p
+        raise RuntimeError("reference CHECK failed: " + lib().ref_conv_last_error().decode())
+    return out
+
+
+def caffe_conv(x, w, b, pad, stride=1):
+    """caffe_conv of src/caffe/test/test_convolution_layer.cpp:21-139: the naive loop the reference's own tests use as ground truth."""
+    return _conv_call(lib().ref_caffe_conv, x, w, b, pad, stride)
+
+
+def im2col_conv(x, w, b, pad, stride=1):
+    """im2col_cpu (src/caffe/util/im2col.cpp:19-55, the reference's) + the GEMM / bias shapes of base_conv_layer.cpp:257-280."""
+    return _conv_call(lib().ref_im2col_conv, x, w, b, pad, stride)
+
+
+def im2col(x, k, pad, stride=1):
+    x = np.ascontiguousarray(x, np.float32)
+    Cin, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    col = np.full((Cin * k * k, Ho * Wo), np.nan, np.float32)
+    lib().ref_im2col(_f(x), Cin, H, W, k, k, pad, pad, stride, stride, _f(col))
+    return col
+
+
+def maxpool(x, k=2, stride=2, pad=0):
+    """The MAX branch of PoolingLayer::Forward_cpu (pooling_layer.cpp:149-186) with Reshape's output size (:90-107)."""
+    x = np.ascontiguousarray(x, np.float32)
+    N, Cc, H, W = x.shape
+    ho, wo = C.c_int(), C.c_int()
+    assert lib().ref_maxpool(_f(x), N, Cc, H, W, k, stride, pad, None, C.byref(ho), C.byref(wo)) == 0
+    out = np.full((N, Cc, ho.value, wo.value), np.nan, np.float32)
+    assert lib().ref_maxpool(_f(x), N, Cc, H, W, k, stride, pad, _f(out), None, None) == 0
+    return out

@@ -31,3 +31,20 @@ def test_bare_gpus_2_spawns_two_ranks_and_prints_one_line():
 def test_single_rank_needs_no_launcher():
     lines = _run(["--gpus", "1"])
     assert len(lines) == 1 and lines[0]["n_gpus"] == 1
+
+
+def test_rccl_failure_falls_back_to_gloo_and_says_so():
+    """bench.py asks for the nccl (= RCCL) process group where torch sees a GPU.  RCCL runs on torch's bundled HIP runtime next to the
+    engine's system runtime; if it cannot start, every rank must fall back to gloo — not hang, not die — and the line must say which
+    backend carried the barrier.  Here (no GPU) --comm nccl fails on every rank at init."""
+    lines = _run(["--gpus", "2", "--comm", "nccl", "--broadcast_weights"])
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["comm_backend"] == "gloo" and "nccl failed" in out["comm_note"] and "fell back to gloo" in out["comm_note"]
+    assert out["n_gpus"] == 2 and len(out["per_rank_frames_per_s"]) == 2 and out["value"] > 0
+    assert out["weight_blob_broadcast_ok"] is True       # the one-time weight-blob broadcast (rank 0 -> all) arrives intact on every rank
+
+
+def test_auto_comm_is_gloo_without_a_gpu():
+    out = _run(["--gpus", "2"])[0]
+    assert out["comm_backend"] == "gloo" and out["comm_note"] is None

@@ -717,3 +717,59 @@ def test_ring_kernel_variants_are_bit_identical():
     assert strip(run(RTP_LIB=exp, RTP_RING_ILV="1")) == strip(base)
     assert strip(run(RTP_LIB=exp, RTP_HALO_SHARED="0")) == strip(base)
     assert strip(run(RTP_RING_VAR="12", RTP_DIAG_SKIP_POST="2")) == strip(base)  # the production library does not know these names
+
+
+# ------------------------------------------------------------------------------------------
+# round 4: caller-owned device buffers, one-time weight distribution
+# ------------------------------------------------------------------------------------------
+def test_engine_owned_device_buffers_feed_submit_device():
+    """rtp_device_alloc / upload / free: net inputs resident in HBM that belong to the ENGINE's HIP runtime (bench.py keeps torch out of
+    the data path with them).  rtp_submit_device on such a buffer == rtp_submit of the same host tensor, bit for bit."""
+    import caffe_rtpose_amd as r
+    e = _engine(net_w=160, net_h=96, precision=r.PREC_MIXED, frames_in_flight=4, batch_frames=2)
+    xs = [_synth.random_frame(1, 96, 160, seed=s_) for s_ in (1, 2)]
+    ptrs = [e.device_frame(x) for x in xs]
+    for i, x in enumerate(xs):
+        e.submit(x, tag=i)
+    want = [e.collect() for _ in xs]
+    for i, p in enumerate(ptrs):
+        e.submit_device(p, tag=10 + i)
+    got = [e.collect() for _ in xs]
+    e.synchronize()
+    for (t0, n0, j0), (t1, n1, j1) in zip(want, got):
+        assert t1 == t0 + 10 and n0 == n1 and np.array_equal(j0, j1)
+    e.device_free(ptrs[0])
+    with pytest.raises(r.RtpError):
+        e.device_free(ptrs[0])          # not (any more) a buffer of this engine
+    e.close()                           # the second buffer goes with the engine
+
+
+def test_weight_blob_and_peer_copy_reproduce_the_source_engine():
+    """The optional one-time weight distribution: a replica that takes another engine's PACKED arena — through the host blob
+    (bench.py --broadcast_weights) or device to device (rtpose.bin --share_weights) — computes the source's maps bit for bit and reports
+    the source's Caffe-layout weights; a blob from another plan is refused."""
+    import caffe_rtpose_amd as r
+    kw = dict(net_w=160, net_h=96, precision=r.PREC_MIXED, frames_in_flight=2, batch_frames=1)
+    src = _engine(synthetic_seed=11, **kw)
+    x = _synth.random_frame(1, 96, 160, seed=4)
+    want = src.forward_heatmaps(x)
+    blob = src.weight_blob()
+    a = _engine(synthetic_seed=1, **kw)
+    assert not np.array_equal(a.forward_heatmaps(x), want)
+    a.load_weight_blob(blob)
+    assert np.array_equal(a.forward_heatmaps(x), want)
+    assert all(np.array_equal(a.get_conv_weights(i)[0], src.get_conv_weights(i)[0]) for i in (0, 17, 91))
+    a.submit(x, tag=3)                  # graphs captured before the import bake the old fp8 weight exponents: they must have been dropped
+    src.submit(x, tag=3)
+    ra, rs = a.collect(), src.collect()
+    assert ra[1] == rs[1] and np.array_equal(ra[2], rs[2])
+    b = _engine(synthetic_seed=2, **kw)
+    b.copy_weights_from(src)
+    assert np.array_equal(b.forward_heatmaps(x), want)
+    other = _engine(synthetic_seed=1, net_w=160, net_h=96, precision=r.PREC_FP16, frames_in_flight=2, batch_frames=1)
+    with pytest.raises(r.RtpError):
+        other.load_weight_blob(blob)    # another plan (precision): refused, nothing written
+    with pytest.raises(r.RtpError):
+        other.copy_weights_from(src)
+    for e in (src, a, b, other):
+        e.close()

@@ -33,6 +33,25 @@ def test_abi_library_exports_every_declared_symbol():
     assert b"gfx950" in r.lib.rtp_version()
 
 
+def test_production_library_has_no_experiment_knobs():
+    """ablation variants of the ring kernel that compute wrong results on purpose, forced tiles, skipped
+    post-processing stages and probes used to be selectable by environment variables in the shipped library.  They live in the second
+    build target now (librtpose_mi355x_exp.so, -DRTP_EXPERIMENTS, used by tools/); in the production library the knobs' NAMES are not
+    even strings in the binary.  The one variable it reads, RTP_EXEC=eager|graph, chooses between two ways of launching the same
+    kernels."""
+    lib = os.path.join(ROOT, "caffe_rtpose_amd", "librtpose_mi355x.so")
+    exp = os.path.join(ROOT, "caffe_rtpose_amd", "librtpose_mi355x_exp.so")
+    names = lambda path: set(re.findall(rb"RTP_[A-Z][A-Z0-9_]+", open(path, "rb").read()))
+    consts = set(re.findall(rb"#define (RTP_[A-Z0-9_]+)", open(HEADER, "rb").read()))   # RTP_PREC_MIXED etc. appear in error messages
+    prod = names(lib) - consts
+    assert prod == {b"RTP_EXEC"}, prod
+    removed = {b"RTP_RING_VAR", b"RTP_FORCE_CFG", b"RTP_TILE_OVERRIDE", b"RTP_DIAG_SKIP_POST", b"RTP_RING_SB", b"RTP_RING_SPEC", b"RTP_POST_CUS", b"RTP_NMS_PROBE",
+               b"RTP_SPLIT_LAYERS", b"RTP_HALO_SHARED", b"RTP_HALF_CHIP", b"RTP_GRAPH_POST", b"RTP_STREAM_PLAN", b"RTP_MATCH_WGS"}
+    assert os.path.exists(exp) and removed <= names(exp)            # the experiments build still has them (tools/, tests of the variants)
+    src = open(os.path.join(ROOT, "caffe_rtpose_amd", "csrc", "engine.cpp")).read() + open(os.path.join(ROOT, "caffe_rtpose_amd", "csrc", "conv_ring.hip")).read()
+    assert re.findall(r"[^_A-Z]getenv\(\"(RTP_[A-Z_]+)\"\)", src.replace("#ifdef RTP_EXPERIMENTS", "")) .count("RTP_EXEC") == 1
+
+
 def test_no_cpu_fallback_when_no_device():
     import torch
     import caffe_rtpose_amd as r

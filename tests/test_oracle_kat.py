@@ -1,8 +1,9 @@
 """Pin the CPU oracle against the reference's own known-answer tests.
 
-Every case below restates a test the reference ships for the standard layers on the hot
-path; the CMU-added layers (ImResize, Nms, connectLimbs*, JSON) have NO reference test, so
-for those we can only check internal properties (see test_oracle_cpm.py) — parity unpinned.
+Every case below restates a test the reference ships for the standard layers on the hot path (and cross-checks torch CPU).  The
+stronger pins live in tests/test_ref_pin.py / tests/test_ref_golden.py: convolution, pooling, ImResize, Nms, connectLimbs*, JSON,
+process_and_pad_image and the renderer are compared with the reference's OWN code (oracle/_ref/libref.so, compiled from
+/root/reference by oracle/ref_recipe/build_ref.sh) and with its stored outputs.
 """
 import numpy as np
 import pytest

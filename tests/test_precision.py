@@ -157,27 +157,39 @@ def _bench_module():
     return m
 
 
-@pytest.mark.parametrize("cfg", ["coco_1s_b2", "coco_3s_b2"])
+@pytest.mark.parametrize("cfg", ["coco_1s_b2", "coco_3s_b2", "mpi_1s_b5"])
 def test_people_level_parity_of_the_benched_mode(cfg):
     """SURVEY section 7 / BASELINE.md section 3 on the configurations bench.py quotes: the engine's joints in the DEFAULT (mixed) mode
-    through rtp_submit / rtp_collect vs the full fp32 oracle chain (conv -> ImResize -> Nms -> connectLimbsCOCO), compared as sets of
-    people (a person as in rtpose.cpp:1051-1073) — the same function that writes bench.py's `parity` dict."""
+    through rtp_submit / rtp_collect vs the full fp32 oracle chain (conv -> ImResize -> Nms -> connectLimbs*), compared as sets of
+    people (a person as in rtpose.cpp:1051-1073) — the same function that writes bench.py's `parity` dict.
+
+    What must hold: no joint that is the same maximum on both sides outside +-1 px / +-1e-3; EVERY structural
+    difference traced to a decision whose reference-side margin is below twice the measured deviation (tests/_explain.py: NMS compares,
+    PAF samples against their threshold, rounding boundaries, order inversions) — none unexplained; and on maps that look like poses
+    (planted people + the engine's measured deviation field) the same people, identical within one net pixel."""
     import caffe_rtpose_amd as r
     bench = _bench_module()
     model, W, H, N, gap, B = CONFIGS[cfg]
     e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, scale_gap=gap, precision=r.PREC_MIXED, frames_in_flight=2 * B, batch_frames=B))
     x, ref = _reference(model, W, H, N, e)
-    rep = bench.parity_report(e, [(x, ref, 0.0)], "coco", N, gap)
-    print(f"\n[parity {cfg}] {rep}")
-    assert not rep["verdict"].startswith("FAIL")
-    assert rep["map_max_err"] <= 1e-3 and rep["max_dc"] <= 1e-3 and rep["max_dx_px"] <= 1.0 and rep["max_dy_px"] <= 1.0
-    assert rep["post_on_engine_maps_bit_exact"]
-    # The random-weight network's maps are noise: ~650 maxima, a handful of them with a margin to a neighbour below the map
-    # tolerance (test_final_maps_and_keypoints_within_tolerance prints them).  Each such flip re-numbers the raster-ordered peaks of
-    # its part and re-routes connectLimbs' greedy picks, so a few PEOPLE differ structurally although every corresponding joint
-    # agrees to a few hundredths of a pixel.  Measured: 62 of 77 people identical, 322 of 348 joints.
-    assert rep["people_ref"] > 20 and rep["joints_matched"] >= 0.85 * rep["joints_ref"]
-    assert rep["people_matched"] >= 0.7 * rep["people_ref"]
+    rep = bench.parity_report(e, [(x, ref, 0.0)], "coco" if model == 0 else "mpi", N, gap)
+    print(f"\n[parity {cfg}] " + ", ".join(f"{k}: {v}" for k, v in rep.items() if k not in ("structured", "units", "reference")))
+    print(f"[parity {cfg}] structured: {rep['structured']}")
+    assert rep["verdict"].startswith(("pass", "numeric pass")), rep["verdict"]
+    assert rep["numeric_out_of_tol"] == 0 and rep["max_dc"] <= 1e-3 and rep["max_dx_px"] <= 1.0 and rep["max_dy_px"] <= 1.0   # (no longer tautologies: taken over every paired joint)
+    assert rep["map_max_err"] <= 1e-3 and rep["post_on_engine_maps_bit_exact"]
+    assert rep["explain"]["unexplained"] == 0, rep["explain"]["unexplained_detail"]
+    assert rep["structural_explained"] == rep["joints_structural"]
+    assert rep["joints_structural"] == 0 or sum(rep["explain"]["root_flips"].values()) > 0
+    assert rep["explain"]["worst_margin_over_allowance"] < 0.8    # the flips are near-ties with room to spare, not decisions at the edge of the allowance
+    # The random-weight network's maps are noise: hundreds of maxima, some of them near-ties.  Each flip re-numbers the raster-ordered
+    # peaks of its part and re-routes connectLimbs' greedy picks, so a few PEOPLE differ structurally although every corresponding joint
+    # agrees to a few hundredths of a pixel; the floor below only guards against a silent collapse of the comparison itself.
+    assert rep["people_ref"] > (20 if model == 0 else 5) and rep["joints_matched"] >= 0.8 * rep["joints_ref"]
+    assert rep["people_matched"] >= 0.6 * rep["people_ref"]
+    st = rep["structured"]
+    assert st["verdict"].startswith("pass"), st
+    assert all(c["identical_within_one_net_pixel"] and c["numeric_out_of_tol"] == 0 and c["people_ref"] == c["people_engine"] >= 1 for c in st["cases"].values())
     e.close()
 
 

@@ -295,6 +295,31 @@ def test_cli_two_workers_share_one_queue(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_four_engines_seven_in_flight_on_one_device(tmp_path):
+    """What the first 8-GPU run does, as far as one GPU can show it: --num_gpu 4 --devices 0,0,0,0 at the benched
+    resolution with 7 frames in flight in batches of 2 per engine — four engines created, calibration-free, graph-captured in four
+    threads AT ONCE, 4 x 4 batch contexts and 4 x 8 streams on one device, --share_weights copies worker 0's packed arena into the
+    other three.  Every frame is written once and the JSON equals the one-worker run byte for byte (per-frame results do not depend on
+    which engine or which batch a frame lands in)."""
+    outs = []
+    for ngpu, extra in ((1, []), (4, ["--devices", "0,0,0,0", "--share_weights"])):
+        out = tmp_path / f"js{ngpu}"
+        p = subprocess.run([BIN, "--video", "synthetic:640x480:56:9", "--model", "coco", "--net_resolution", "656x368", "--write_json", str(out), "--no_frame_drops",
+                            "--no_display", "--num_gpu", str(ngpu), "--frames_in_flight", "7", "--batch_frames", "2"] + extra, capture_output=True, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        counts = _worker_counts(p.stderr)
+        assert len(counts) == ngpu and sum(counts) == 56, p.stderr.decode()[-2000:]
+        if ngpu == 4:
+            assert min(counts) > 0, f"a worker never got a frame: {counts}"
+            assert b"share_weights: 3 worker(s) took worker 0's packed weights" in p.stderr
+        outs.append(out)
+    files = sorted(os.listdir(outs[0]))
+    assert files == [f"frame{i:06d}.json" for i in range(56)] == sorted(os.listdir(outs[1]))
+    for f in files:
+        assert open(outs[0] / f, "rb").read() == open(outs[1] / f, "rb").read(), f
+
+
+@pytest.mark.gpu
 def test_cli_frame_drops_and_no_frame_drops(tmp_path):
     """processFrame drops a frame that waited > 0.1 s for a GPU (rtpose.cpp:1112-1124) and the re-orderer skips its
     index; --no_frame_drops disables that.  A slow worker (test hook: 60 ms per frame) makes the queue back up."""

@@ -27,6 +27,18 @@ def _sha(name):
     return G[name].tobytes().decode()
 
 
+def test_oracle_conv_and_pool_reproduce_the_reference_outputs():
+    """The conv / pool half of the oracle against what the reference's own caffe_conv, im2col_cpu (+ GEMM) and pooling loop returned
+    (tools/make_ref_golden.py ran them in the build container; here — and on the GPU box — only their outputs are needed)."""
+    for name, x, w, b, pad, stride in pc.conv_cases():
+        got = orc.conv2d(x, w, b, pad, stride)
+        naive, gemm = G[f"conv_{name}_naive"], G[f"conv_{name}_im2col"]
+        scale = max(1.0, float(np.abs(naive).max()))
+        assert got.shape == naive.shape and np.abs(got - naive).max() <= 1e-4 * scale and np.abs(got - gemm).max() <= 2e-5 * scale, name
+    for name, x, k, stride, pad in pc.pool_cases():
+        assert np.array_equal(orc.maxpool(x, k, stride, pad), G[f"pool_{name}"]), name
+
+
 def test_oracle_reproduces_the_reference_outputs():
     tables = _tables()
     for m in (0, 1):

@@ -110,3 +110,42 @@ def test_views_bit_equal(tables):
             got = orc.render_view(model, img, maps, part)
             assert np.array_equal(got, want), f"{name} part_to_show {part}: {int((got != want).any(-1).sum())} pixels differ"
             assert (want != img).any(), (name, part)
+
+
+# ---- the conv / pool half of the oracle, pinned on reference-held code --------------------------------------
+def test_conv_equals_the_references_own_caffe_conv_and_im2col_path():
+    """orc.conv2d (Caffe's CPU convolution restated: im2col K order, fp32) against (a) caffe_conv, the naive loop the reference's own
+    convolution tests trust (test_convolution_layer.cpp:21-139, compiled from the reference tree), at the tolerance those tests use
+    (1e-4), and (b) the reference's im2col_cpu (im2col.cpp:19-55) followed by the GEMM / bias shapes of forward_cpu_gemm — same K order,
+    so the two agree to the rounding of a different summation blocking."""
+    for name, x, w, b, pad, stride in pc.conv_cases():
+        got = orc.conv2d(x, w, b, pad, stride)
+        naive = _ref.caffe_conv(x, w, b, pad, stride)
+        gemm = _ref.im2col_conv(x, w, b, pad, stride)
+        assert got.shape == naive.shape == gemm.shape and np.isfinite(naive).all() and np.isfinite(gemm).all(), name
+        scale = max(1.0, float(np.abs(naive).max()))
+        assert np.abs(got - naive).max() <= 1e-4 * scale, (name, float(np.abs(got - naive).max()))
+        assert np.abs(got - gemm).max() <= 2e-5 * scale, (name, float(np.abs(got - gemm).max()))
+        assert np.abs(naive - gemm).max() <= 1e-4 * scale, name          # the reference agrees with itself
+
+
+def test_im2col_buffer_is_the_k_order_the_oracle_documents():
+    """K index of the im2col buffer = (cin * kh + r) * kw + s, spatial index = y * W_out + x (im2col.cpp:19-55): the order the oracle's
+    convolution (and the engine's weight packing, which starts from Caffe's [cout][cin][kh][kw] blob) assumes."""
+    rs = np.random.RandomState(3)
+    x = rs.randn(3, 5, 6).astype(np.float32)
+    col = _ref.im2col(x, 3, 1)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1)))
+    for c in range(3):
+        for r in range(3):
+            for s_ in range(3):
+                assert np.array_equal(col[(c * 3 + r) * 3 + s_].reshape(5, 6), xp[c, r:r + 5, s_:s_ + 6])
+
+
+def test_maxpool_equals_the_references_pooling_loop():
+    for name, x, k, stride, pad in pc.pool_cases():
+        want = _ref.maxpool(x, k, stride, pad)
+        got = orc.maxpool(x, k, stride, pad)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    y = _ref.maxpool(next(pc.pool_cases())[1], 2, 1, 0)
+    assert np.array_equal(y[0, 0], np.array([[9, 5, 5, 8], [9, 5, 5, 8]], np.float32))   # TestForwardSquare's expected answer

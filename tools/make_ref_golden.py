@@ -44,6 +44,12 @@ for name, model, img, maps, parts in pc.view_cases(tables):
     for part in parts:
         out[f"view_{name}_{part}"] = _ref.render(model, img, np.zeros((1, pc.DIMS[model][0], 3), np.float32), 0, maps.shape[2], maps.shape[1],
                                                  part_to_show=part, heatmaps=maps)
+# convolution / pooling: caffe_conv (the naive loop of the reference's own tests), im2col_cpu + GEMM, the MAX loop of PoolingLayer::Forward_cpu
+for name, x, w, b, pad, stride in pc.conv_cases():
+    out[f"conv_{name}_naive"] = _ref.caffe_conv(x, w, b, pad, stride)
+    out[f"conv_{name}_im2col"] = _ref.im2col_conv(x, w, b, pad, stride)
+for name, x, k, stride, pad in pc.pool_cases():
+    out[f"pool_{name}"] = _ref.maxpool(x, k, stride, pad)
 path = os.path.join(ROOT, "tests", "golden", "ref_pin.npz")
 np.savez_compressed(path, **out)
 print(f"wrote {path}: {os.path.getsize(path)} bytes, {len(out)} arrays")
