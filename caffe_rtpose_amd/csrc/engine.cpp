@@ -22,6 +22,7 @@
 #include <deque>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -43,6 +44,14 @@ extern "C" int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int 
 namespace {
 
 thread_local std::string g_create_error = "";
+
+// HIP refuses every synchronous legacy-stream operation (hipMemset, hipMemcpy, hipDeviceSynchronize, ...) of ANY thread while ANY
+// stream of the process is capturing a graph ("operation would make the legacy stream depend on a capturing blocking stream"), whatever
+// the capture mode.  One engine per worker thread (rtpose.cpp:1463-1472) means engines are created, captured and torn down concurrently:
+// every capture and every such synchronous operation of this library happens under this one process-wide lock.  The per-frame path
+// (async copies, launches, event waits on the engine's own streams) never takes it.  Found by rtpose.bin --num_gpu 4 --devices 0,0,0,0.
+std::recursive_mutex g_sync_mutex;
+#define SYNC_GUARD std::lock_guard<std::recursive_mutex> sync_guard_(g_sync_mutex)
 
 struct Tensor {
   std::string name;
@@ -74,6 +83,7 @@ struct ConvOp {
   bool direct_first = false;  // conv1_1 straight from the NCHW input (conv_first.hip): no im2col tensor, no pack step
   // split precision (RTP_PREC_MIXED / F16X3): the K loop runs the passes [a_hi x W_hi] [a_lo x W_hi] [a_hi x W_lo]
   bool split_a = false, split_w = false;
+  bool no_h8 = false;       // rule suffix ":x": the corrections of this layer run as fp16 passes even where the fp8 chunk exists (no e4m3 range limits)
   int ncp = 1;              // chunks of ONE pass (nchunk = ncp * passes)
   bool h8 = false;          // the two correction passes run as ONE fp8 chunk per channel group (MX-scaled MFMA, 2x the fp16 rate)
   int wq_exp = 0;           // h8: fp8(W * 2^wq_exp), fp8(W_lo * 2^(wq_exp + 11))
@@ -241,8 +251,9 @@ const int GUARD_PIX = 192;  // pixels of slack before/after each tensor (strip o
 //   + stage 4 (this default, 2.35x MFMA)     rms 1.03e-4  max <= 0.8e-3
 //   every layer (RTP_PREC_F16X3, 3x MFMA)    rms 1.6e-6   max 1e-5
 const char* kDefaultSplit = "conv2_,conv3_,conv4_,*_stage4_,*_stage5_,*_stage6_,@1x1";
-void layer_split(const rtp_engine* e, const ConvOp& c, bool* w, bool* a) {
+void layer_split(const rtp_engine* e, const ConvOp& c, bool* w, bool* a, bool* x = nullptr) {
   *w = *a = false;
+  if (x) *x = false;
   if (e->prec != 0) return;
   if (e->mode == RTP_PREC_F16X3) { *w = *a = true; return; }
   if (e->mode != RTP_PREC_MIXED) return;
@@ -253,19 +264,20 @@ void layer_split(const rtp_engine* e, const ConvOp& c, bool* w, bool* a) {
     std::string tok = rules.substr(pos, c2 == std::string::npos ? std::string::npos : c2 - pos);
     pos = c2 == std::string::npos ? rules.size() + 1 : c2 + 1;
     if (tok.empty()) continue;
-    bool tw = true, ta = true;
+    bool tw = true, ta = true, tx = false;
     if (tok.size() > 2 && tok[tok.size() - 2] == ':') {
       const char k = tok.back();
       tok.resize(tok.size() - 2);
       if (k == 'w') ta = false;
       else if (k == 'a') tw = false;
+      else if (k == 'x') tx = true;   // both operands, corrections as two more fp16 passes (what RTP_PREC_F16X3 runs everywhere)
     }
     bool hit;
     if (tok == "@all") hit = true;
     else if (tok == "@1x1") hit = c.k == 1;
     else if (tok[0] == '*') hit = c.name.find(tok.substr(1)) != std::string::npos;
     else hit = c.name.compare(0, tok.size(), tok) == 0;
-    if (hit) { *w = *w || tw; *a = *a || ta; }
+    if (hit) { *w = *w || tw; *a = *a || ta; if (x) *x = *x || tx; }
   }
 }
 
@@ -472,7 +484,7 @@ int build_plan(rtp_engine* e) {
 
   // split precision: which layers, then which tensors must carry a lo block
   for (auto& c : e->convs) {
-    layer_split(e, c, &c.split_w, &c.split_a);
+    layer_split(e, c, &c.split_w, &c.split_a, &c.no_h8);
     if (c.first) c.split_a = false;  // the image (u8/256 - 0.5) is exact in fp16: its lo part is zero
   }
 
@@ -532,7 +544,7 @@ int build_plan(rtp_engine* e) {
     const bool rule_r2 = tm && !strcmp(tm, "r2");
     long best_wg = -1;
     bool chosen = false;
-    const int passes = (A.split_a || A.split_w) ? ((e->split_fp8 && e->mode == RTP_PREC_MIXED && A.split_a && A.split_w && ring_ok) ? 2 : 1 + (A.split_a ? 1 : 0) + (A.split_w ? 1 : 0)) : 1;
+    const int passes = (A.split_a || A.split_w) ? ((e->split_fp8 && e->mode == RTP_PREC_MIXED && A.split_a && A.split_w && !A.no_h8 && ring_ok) ? 2 : 1 + (A.split_a ? 1 : 0) + (A.split_w ? 1 : 0)) : 1;
     for (int cf : cands) {
       const ConvCfgInfo ci = conv_cfg_info(cf);
       const long wg = ((M + ci.BM - 1) / ci.BM) * e->NI * (round_up(maxcout, ci.BN) / ci.BN) * nprob;
@@ -621,7 +633,7 @@ int build_plan(rtp_engine* e) {
     // k-split of the kernel that would run it (conv_ring.hip; q layers on the 64x64 tile with 128-byte chunks get a 2-way split)
     const int ksplit = c.cfg == CFG_128x128 ? 1 : (c.cfg == CFG_64x64 ? (c.rowb == 128 ? 2 : 4) : 2);
     const int gpw = (c.rowb / 32) / ksplit;
-    c.h8 = e->split_fp8 && e->mode == RTP_PREC_MIXED && e->prec == 0 && c.impl == 1 && c.split_a && c.split_w && gpw >= 2 && gpw % 2 == 0;
+    c.h8 = e->split_fp8 && e->mode == RTP_PREC_MIXED && e->prec == 0 && c.impl == 1 && c.split_a && c.split_w && !c.no_h8 && gpw >= 2 && gpw % 2 == 0;
   }
   for (auto& s : e->steps)  // both branches of a pair run the same kernel
     if (s.type == 1 && s.b >= 0 && e->convs[s.a].h8 != e->convs[s.b].h8)
@@ -888,6 +900,7 @@ int upload_conv_weights(rtp_engine* e, int i) {
   std::vector<float> pb;
   if (e->prec == 0) pack_conv<_Float16>(e, c, e->w_ref[i], e->b_ref[i], &pw, &pb);
   else pack_conv<float>(e, c, e->w_ref[i], e->b_ref[i], &pw, &pb);
+  SYNC_GUARD;   // (the packing above, the expensive part, runs in parallel across engines)
   HIPCHK(e, hipMemcpy(e->dweights + c.w_off, pw.data(), pw.size(), hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(e->dweights + c.b_off, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
   return RTP_OK;
@@ -1189,6 +1202,7 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
     if (e->cfg.render && sl.has_disp) {  // pose overlay on the display image (renderFunctions.cu, part_to_show == 0)
       const size_t dbytes = (size_t)e->cfg.disp_w * e->cfg.disp_h * 3;
       if (!sl.render_dev) {
+        SYNC_GUARD;
         HIPCHK(e, hipMalloc((void**)&sl.render_dev, dbytes));
         HIPCHK(e, hipHostMalloc((void**)&sl.render_host, dbytes, hipHostMallocDefault));
         HIPCHK(e, hipMalloc((void**)&sl.render_tab, render_tab_floats(RTP_MAX_PEOPLE) * sizeof(float)));
@@ -1221,6 +1235,7 @@ int launch_batch_body(rtp_engine* e, Ctx& cx, int nframes, const float* input_de
 // this context (stream capture of exactly the eager sequence; the frame slots' streams fork from and
 // join the context's stream), then ONE hipGraphLaunch per batch.  Replaces net.cpp:544-556.
 int capture_batch(rtp_engine* e, Ctx& cx, int nframes, hipGraphExec_t* out) {
+  SYNC_GUARD;
   hipGraph_t g = nullptr;
   HIPCHK(e, hipStreamBeginCapture(cx.stream, hipStreamCaptureModeThreadLocal));
   const int rc = launch_batch_body(e, cx, nframes, cx.input, false, true, e->graph_post ? 3 : 1);
@@ -1394,6 +1409,7 @@ int use_device(rtp_engine* e) {
 // RTP_GRAPH_POST=1 also the thresholds and scales of the post-processing chains).  Whoever changes one of those drops the
 // graphs; launch_batch re-captures on the next batch.  Needs an idle engine.
 int invalidate_graphs(rtp_engine* e) {
+  SYNC_GUARD;
   for (Ctx& cx : e->ctx) {
     if (cx.stream) HIPCHK(e, hipStreamSynchronize(cx.stream));
     for (hipGraphExec_t& g : cx.gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
@@ -1403,6 +1419,7 @@ int invalidate_graphs(rtp_engine* e) {
 
 // INTER_AREA tables of every pyramid level (display resolution -> 16*ceil(net*s/16)) + cubic table
 int build_prep_tables(rtp_engine* e) {
+  SYNC_GUARD;
   e->gpu_prep_ok = false;
   struct Host { int tw, th, identity, fx = 0, fy = 0; std::vector<int> xs, xsi, ys, ysi; std::vector<float> xa, ya; };
   std::vector<Host> hs(e->N);
@@ -1456,7 +1473,8 @@ int build_prep_tables(rtp_engine* e) {
 int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr, int w, int h, float* frame_scale) {
   Slot& sl = cx.slot[sj];
   const size_t fbytes = (size_t)w * h * 3;
-  if (fbytes > sl.frame_cap) {
+  if (fbytes > sl.frame_cap) {   // first frame of this slot (or a larger one): rare, and hipFree synchronises the device
+    SYNC_GUARD;
     HIPCHK(e, hipStreamSynchronize(cx.stream));
     if (sl.frame_dev) (void)hipFree(sl.frame_dev);
     if (sl.frame_host) (void)hipHostFree(sl.frame_host);
@@ -1465,7 +1483,7 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
     HIPCHK(e, hipHostMalloc((void**)&sl.frame_host, fbytes, hipHostMallocDefault));
     sl.frame_cap = fbytes;
   }
-  if (!sl.disp_dev) HIPCHK(e, hipMalloc((void**)&sl.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3));
+  if (!sl.disp_dev) { SYNC_GUARD; HIPCHK(e, hipMalloc((void**)&sl.disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3)); }
   const double s = rtp_display_fit_scale(w, h, e->cfg.disp_w, e->cfg.disp_h);
   if (frame_scale) *frame_scale = (float)s;
   memcpy(sl.frame_host, bgr, fbytes);
@@ -1482,6 +1500,7 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
   int rc;
   if ((rc = use_device(e))) return rc;
   {
+    SYNC_GUARD;
     hipError_t s = hipMalloc((void**)&e->dweights, e->weights_bytes);
     if (s != hipSuccess) { e->dweights = nullptr; return fail(e, RTP_ENOMEM, "hipMalloc(%zu) for weights failed: %s", e->weights_bytes, hipGetErrorString(s)); }
     s = hipMemset(e->dweights, 0, e->weights_bytes);
@@ -1494,6 +1513,7 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
   compute_wq_exp(e);
   for (size_t i = 0; i < e->convs.size(); ++i)
     if ((rc = upload_conv_weights(e, (int)i))) return rc;
+  SYNC_GUARD;   // contexts (hipMemset of the arenas), the dry run's synchronisation, the graph captures
   e->ctx.resize(nctx);
   for (auto& c : e->ctx)
     if ((rc = alloc_ctx(e, c))) return rc;
@@ -1518,6 +1538,7 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
 // Drop the plan and everything on the device that was laid out for it; the reference weights (w_ref / b_ref), thresholds, scales and
 // the pre-processing tables stay.
 void drop_plan(rtp_engine* e) {
+  SYNC_GUARD;
   (void)hipSetDevice(e->cfg.device_id);
   (void)hipDeviceSynchronize();
   for (auto& c : e->ctx) free_ctx(c);
@@ -1606,6 +1627,7 @@ const char* rtp_last_error(const rtp_engine* e) { return e ? e->err.c_str() : g_
 
 void rtp_engine_destroy(rtp_engine* e) {
   if (!e) return;
+  SYNC_GUARD;
   (void)hipSetDevice(e->cfg.device_id);
   for (auto& c : e->ctx) free_ctx(c);
   if (e->dweights) (void)hipFree(e->dweights);
@@ -1738,6 +1760,7 @@ int rtp_engine_info(const rtp_engine* e, int* num_parts, int* max_peaks, int* he
 static int need_idle(rtp_engine* e);
 int rtp_set_thresholds(rtp_engine* e, float nms_threshold, float connect_inter_threshold, int connect_inter_min_above_threshold,
                        int connect_min_subset_cnt, float connect_min_subset_score) {
+  SYNC_GUARD;
   if (!e) return RTP_EINVAL;
   if (e->graph_post && !e->ctx.empty()) {  // the post-processing chains live inside the batch graphs: their arguments are baked
     int rc;
@@ -1761,6 +1784,7 @@ int rtp_get_thresholds(const rtp_engine* e, float* a, float* b, int* c, int* d, 
   return RTP_OK;
 }
 int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap) {
+  SYNC_GUARD;
   if (!e) return RTP_EINVAL;
   e->start_scale = start_scale;
   e->scale_gap = scale_gap;
@@ -1841,6 +1865,7 @@ int rtp_flush(rtp_engine* e) {
 static int need_idle(rtp_engine* e);
 // Parity tap: the device pre-processing alone (net input and display image back on the host).
 int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, float* net_input, unsigned char* display_bgr, float* frame_scale) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!bgr || w < 1 || h < 1) return RTP_EINVAL;
@@ -1929,6 +1954,7 @@ static int need_idle(rtp_engine* e) {
 }
 
 int rtp_forward_debug(rtp_engine* e, const float* h_in, float* lowres, float* resized, float* peaks, float* joints, int* num_people) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!h_in) return RTP_EINVAL;
@@ -1952,6 +1978,7 @@ int rtp_forward_debug(rtp_engine* e, const float* h_in, float* lowres, float* re
 }
 
 int rtp_forward_heatmaps(rtp_engine* e, const float* h_in, float* lowres) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!h_in || !lowres) return RTP_EINVAL;
@@ -1965,6 +1992,7 @@ int rtp_forward_heatmaps(rtp_engine* e, const float* h_in, float* lowres) {
 }
 
 int rtp_resize(rtp_engine* e, const float* lowres, float* resized) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!lowres || !resized) return RTP_EINVAL;
@@ -1978,6 +2006,7 @@ int rtp_resize(rtp_engine* e, const float* lowres, float* resized) {
 
 // Parity tap for the PRODUCTION post-processing (no resized map): low-res maps in, peaks and joints out.
 int rtp_post_from_lowres(rtp_engine* e, const float* lowres, float* peaks, float* joints, int* num_people) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!lowres) return RTP_EINVAL;
@@ -2021,6 +2050,7 @@ int rtp_post_from_lowres(rtp_engine* e, const float* lowres, float* peaks, float
 }
 
 int rtp_nms(rtp_engine* e, const float* resized, float* peaks) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!resized || !peaks) return RTP_EINVAL;
@@ -2035,6 +2065,7 @@ int rtp_nms(rtp_engine* e, const float* resized, float* peaks) {
 }
 
 int rtp_connect(rtp_engine* e, const float* resized, const float* peaks, float* joints, int* num_people) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!resized || !peaks) return RTP_EINVAL;
@@ -2054,6 +2085,7 @@ int rtp_connect(rtp_engine* e, const float* resized, const float* peaks, float* 
 // render() of rtpose.cpp:270-299 on caller data: the pose overlay or one of the --part_to_show views
 int rtp_render(rtp_engine* e, const unsigned char* display_bgr, const float* joints, int num_people, int part_to_show, int googly,
                const float* resized_host, unsigned char* out_bgr) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!display_bgr || !out_bgr || num_people < 0 || (num_people > 0 && !joints)) return RTP_EINVAL;
@@ -2095,6 +2127,7 @@ int rtp_render(rtp_engine* e, const unsigned char* display_bgr, const float* joi
 }
 
 int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int shape[4]) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!name) return RTP_EINVAL;
@@ -2147,6 +2180,7 @@ int rtp_get_conv_weights(const rtp_engine* e, int i, float* w, float* b) {
   return RTP_OK;
 }
 int rtp_set_conv_weights(rtp_engine* e, int i, const float* w, const float* b) {
+  SYNC_GUARD;
   if (!e || i < 0 || i >= (int)e->convs.size() || !w || !b) return RTP_EINVAL;
   int rc;
   if ((rc = need_idle(e))) return rc;
@@ -2395,6 +2429,7 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
 }
 
 int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launches, double* flops_per_launch) {
+  SYNC_GUARD;
   if (!e) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
@@ -2457,6 +2492,7 @@ int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches
 // Diagnostics: every step of the plan alone on the chip, `iters` back-to-back launches at the full
 // batch; ms[i] = average launch time of step i, gflop[i] = its convolution work (0 for pack/pool).
 int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int cap) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (iters < 1) return RTP_EINVAL;
@@ -2504,6 +2540,7 @@ int rtp_profile_steps(rtp_engine* e, int iters, float* ms, double* gflop, int ca
 }
 
 int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flops_per_launch) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (e->dominant_step < 0 || iters < 1) return fail(e, RTP_EINVAL, "no 7x7 128->128 convolution step in this graph");
@@ -2548,6 +2585,7 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
 // device from the ENGINE's HIP runtime, for rtp_submit_device.  (A process that also loads another HIP runtime — torch's wheel bundles
 // its own — must not hand that runtime's pointers to this library and expect the two to agree about streams; bench.py allocates here.)
 int rtp_device_alloc(rtp_engine* e, size_t bytes, void** dptr) {
+  SYNC_GUARD;
   if (!e || !dptr || bytes == 0) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
@@ -2559,6 +2597,7 @@ int rtp_device_alloc(rtp_engine* e, size_t bytes, void** dptr) {
   return RTP_OK;
 }
 int rtp_device_free(rtp_engine* e, void* dptr) {
+  SYNC_GUARD;
   if (!e || !dptr) return RTP_EINVAL;
   auto it = std::find(e->user_bufs.begin(), e->user_bufs.end(), dptr);
   if (it == e->user_bufs.end()) return fail(e, RTP_EINVAL, "rtp_device_free: not a buffer of this engine");
@@ -2569,6 +2608,7 @@ int rtp_device_free(rtp_engine* e, void* dptr) {
   return RTP_OK;
 }
 int rtp_device_upload(rtp_engine* e, void* dst_device, const void* src_host, size_t bytes) {
+  SYNC_GUARD;
   if (!e || !dst_device || !src_host) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
@@ -2576,6 +2616,7 @@ int rtp_device_upload(rtp_engine* e, void* dst_device, const void* src_host, siz
   return RTP_OK;
 }
 int rtp_device_synchronize(rtp_engine* e) {
+  SYNC_GUARD;
   if (!e) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
@@ -2612,6 +2653,7 @@ int rtp_device_local_cpus(int device_id, char* buf, size_t buflen) {
 // error most is promoted; when every group is in and the error still exceeds the target the engine falls back to F16X3.
 int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes, float target, char* rules_out, size_t rules_len,
                             float* err_before, float* err_after) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (e->mode != RTP_PREC_MIXED) return fail(e, RTP_EINVAL, "rtp_calibrate_precision adjusts the split set of RTP_PREC_MIXED (engine precision is %d)", e->mode);
@@ -2653,25 +2695,6 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
     *err = m / norm;
     return RTP_OK;
   };
-  // the layer groups a rule can promote: trunk blocks by their "convN_" prefix, stage 1, the refinement stages
-  std::vector<std::string> groups;
-  {
-    std::vector<std::string> all;
-    auto add = [&](const std::string& g) { if (std::find(all.begin(), all.end(), g) == all.end()) all.push_back(g); };
-    for (auto& c : e->convs) {
-      const size_t st = c.name.find("_stage");
-      if (st != std::string::npos) { size_t en = st + 6; while (en < c.name.size() && isdigit((unsigned char)c.name[en])) ++en; add("*" + c.name.substr(st, en - st) + "_"); }
-      else { const size_t us = c.name.find('_'); add(us == std::string::npos ? c.name : c.name.substr(0, us + 1)); }
-    }
-    for (auto& g : all) {   // groups with at least one layer that is not fully split yet
-      bool open = false;
-      for (auto& c : e->convs) {
-        const bool in_g = g[0] == '*' ? c.name.find(g.substr(1)) != std::string::npos : c.name.compare(0, g.size(), g) == 0;
-        if (in_g && !(c.split_w && (c.split_a || c.first))) open = true;
-      }
-      if (open) groups.push_back(g);
-    }
-  }
   std::ostringstream rep;
   std::string rules = base_rules;
   double err = 0;
@@ -2679,7 +2702,28 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   if ((rc = measure(&err))) return rc;
   if (err_before) *err_before = (float)err;
   rep << "target " << target << "; frames " << nframes << "; set \"" << rules << "\" err " << err;
-  bool last_is_current = true;
+  // the layer groups a rule can name: trunk blocks by their "convN_" prefix, stage 1, the refinement stages (from the MIXED plan's flags)
+  std::vector<std::string> all_groups;
+  {
+    auto add = [&](const std::string& g) { if (std::find(all_groups.begin(), all_groups.end(), g) == all_groups.end()) all_groups.push_back(g); };
+    for (auto& c : e->convs) {
+      const size_t st = c.name.find("_stage");
+      if (st != std::string::npos) { size_t en = st + 6; while (en < c.name.size() && isdigit((unsigned char)c.name[en])) ++en; add("*" + c.name.substr(st, en - st) + "_"); }
+      else { const size_t us = c.name.find('_'); add(us == std::string::npos ? c.name : c.name.substr(0, us + 1)); }
+    }
+  }
+  auto in_group = [](const std::string& g, const ConvOp& c) { return g[0] == '*' ? c.name.find(g.substr(1)) != std::string::npos : c.name.compare(0, g.size(), g) == 0; };
+  auto open_groups = [&](bool want_h8) {   // groups with a layer that is not fully split yet (stage 1) / that still runs an fp8 chunk (stage 2)
+    std::vector<std::string> gs;
+    for (auto& g : all_groups) {
+      bool open = false;
+      for (auto& c : e->convs) if (in_group(g, c) && (want_h8 ? c.h8 : !(c.split_w && (c.split_a || c.first)))) open = true;
+      if (open) gs.push_back(g);
+    }
+    return gs;
+  };
+  // stage 1: promote un-split groups, the one that lowers the error most first
+  std::vector<std::string> groups = open_groups(false);
   while (err > target && !groups.empty()) {
     int best = -1;
     double best_err = 1e300;
@@ -2692,15 +2736,36 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
     }
     rules += "," + groups[best];
     rep << "; promote " << groups[best];
-    last_is_current = (best == (int)groups.size() - 1);
     groups.erase(groups.begin() + best);
     err = best_err;
   }
-  (void)last_is_current;
+  // stage 2: every group is split and the target is still missed — the fp8 correction chunks are the limit (e4m3 operands: activations
+  // beyond +-112 or rounding errors beyond their range saturate; 3 mantissa bits).  Groups switch to fp16 correction passes (":x"),
+  // ranked by what the switch gains alone, applied cumulatively until the target holds.
+  if (err > target) {
+    if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return rc;
+    std::vector<std::string> hg = open_groups(true);
+    std::vector<std::pair<double, std::string>> gain;
+    for (auto& g : hg) {
+      double eg = 0;
+      if ((rc = replan(e, RTP_PREC_MIXED, rules + "," + g + ":x", true))) return rc;
+      if ((rc = measure(&eg))) return rc;
+      rep << "; try " << g << ":x -> " << eg;
+      gain.push_back({eg, g});
+    }
+    std::sort(gain.begin(), gain.end());
+    for (auto& ge : gain) {
+      if (err <= target) break;
+      rules += "," + ge.second + ":x";
+      if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return rc;
+      if ((rc = measure(&err))) return rc;
+      rep << "; switch " << ge.second << ":x -> " << err;
+    }
+  }
   int final_mode = RTP_PREC_MIXED;
-  if (err > target) {   // every group is split and the fp8-compensated set still misses the target: every layer as three fp16 passes
+  if (err > target) {   // every layer runs three fp16 passes already where it can: the parity-grade mode for all of them
     final_mode = RTP_PREC_F16X3;
-    rep << "; every group promoted, err " << err << " > target: falling back to RTP_PREC_F16X3";
+    rep << "; err " << err << " > target with every group switched: falling back to RTP_PREC_F16X3";
     err = 0;
   }
   if ((rc = replan(e, final_mode, rules, false))) return rc;
@@ -2746,6 +2811,7 @@ long rtp_weight_blob_bytes(const rtp_engine* e) {
   return (long)(4 * sizeof(uint64_t) + e->convs.size() * sizeof(int) + e->weights_bytes + ref_floats(e) * sizeof(float));
 }
 int rtp_weight_blob_export(rtp_engine* e, void* host, size_t capacity) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!host || (long)capacity < rtp_weight_blob_bytes(e)) return fail(e, RTP_EINVAL, "weight blob needs %ld bytes", rtp_weight_blob_bytes(e));
@@ -2761,6 +2827,7 @@ int rtp_weight_blob_export(rtp_engine* e, void* host, size_t capacity) {
   return RTP_OK;
 }
 int rtp_weight_blob_import(rtp_engine* e, const void* host, size_t bytes) {
+  SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
   if (!host || (long)bytes < rtp_weight_blob_bytes(e)) return fail(e, RTP_EINVAL, "weight blob too short (%zu bytes, this plan needs %ld)", bytes, rtp_weight_blob_bytes(e));
@@ -2783,6 +2850,7 @@ int rtp_weight_blob_import(rtp_engine* e, const void* host, size_t bytes) {
 }
 // dst takes src's packed arena device-to-device (hipMemcpyPeer: xGMI between two GPUs of a node); both engines idle, same plan.
 int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src) {
+  SYNC_GUARD;
   if (!dst || !src) return RTP_EINVAL;
   int rc;
   if ((rc = need_idle(dst))) return rc;

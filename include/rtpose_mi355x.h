@@ -89,9 +89,12 @@ typedef struct rtp_config {
   int exec_mode;           /* RTP_EXEC_*: how a batch's ~45 launches reach the GPU.  Replaces the  *
                             * reference's per-call layer walk (net.cpp:544-556 ForwardFromTo).       */
   const char* split_layers;/* RTP_PREC_MIXED only; NULL = default set.  Comma-separated rules, each *
-                            * "<pattern>[:w|:a]": pattern = layer-name prefix, "*text" = name        *
+                            * "<pattern>[:w|:a|:x]": pattern = layer-name prefix, "*text" = name      *
                             * contains text, "@1x1" = every 1x1 layer, "@all"; ":w" splits only the  *
-                            * weights, ":a" only the input activations, none = both.                  */
+                            * weights, ":a" only the input activations, none = both; ":x" = both,    *
+                            * with the corrections as fp16 passes instead of the fp8 chunk (three     *
+                            * pass-times, no e4m3 range limits: what the calibration switches a      *
+                            * group to when the fp8 corrections are not accurate enough).             */
   int keep_blobs;          /* 0 (default): blobs that only feed a fused consumer are not written (the     *
                             * convolutions in front of the three pooling layers pool in their epilogue):    *
                             * rtp_get_blob("conv1_2" / "conv2_2" / "conv3_4") then returns RTP_EINVAL —      *
@@ -221,7 +224,8 @@ int rtp_save_prototxt(const rtp_engine* e, const char* path);
  * run through RTP_PREC_F16X3 (every layer split: 1e-5-class reference) and through the current mixed plan;
  * err = max |mixed - f16x3| / max |f16x3| over the final maps.  While err > target (<= 0: 0.7e-3) the layer group whose
  * promotion lowers the error most joins the split set and the engine is re-planned (arena, packed weights, graphs); if every
- * group is in and the target is still missed the engine switches to RTP_PREC_F16X3.  rules_out (may be NULL) receives the
+ * group is in and the target is still missed, groups switch their corrections from the fp8 chunk to fp16 passes (":x": e4m3
+ * operands saturate beyond +-112 in the activations), best first; as a last resort the engine switches to RTP_PREC_F16X3.  rules_out (may be NULL) receives the
  * final rule list ("@f16x3" after the fallback), err_before / err_after the measured errors.  Idle engine only; seconds. */
 int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes, float target, char* rules_out, size_t rules_len,
                             float* err_before, float* err_after);

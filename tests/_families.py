@@ -4,7 +4,8 @@ synthetic set is their spectrum, so four families with very different ones:
 
   student_t            heavy tails: t(3) entries (a few weights 10-30x the rms: the fp16 rounding of a weight tile is dominated by them)
   lognormal_channels   per-output-channel scales spanning 100x (log-normal, sigma 1.15): what batch-norm folding leaves in real nets
-  decaying_spectrum    every layer = A diag(r^-1) B with rank <= 64: the power-law singular spectrum of trained VGG-like layers
+  decaying_spectrum    every layer = A diag(r^-0.7) B (rank <= 128) + a Gaussian floor of a quarter of its norm: the power-law singular
+                       spectrum of trained VGG-like layers (a few directions carry most of the energy) without being rank-deficient
   seed5                the engine's own generator with another seed (rtp_config.synthetic_seed = 5)
 
 Activations must stay in fp16 range through ~50 sequential layers whatever the family, so each layer is rescaled LSUV-style on one
@@ -27,9 +28,10 @@ def raw_weights(family, name, cout, cin, k, seed):
         s = np.exp(rs.randn(cout) * 1.15)
         w = rs.randn(cout, fan) * s[:, None]
     elif family == "decaying_spectrum":
-        R = min(cout, fan, 64)
+        R = min(cout, fan, 128)
         a, b = rs.randn(cout, R), rs.randn(R, fan)
-        w = (a * (np.arange(1, R + 1, dtype=np.float64) ** -1.0)[None]) @ b
+        w = (a * (np.arange(1, R + 1, dtype=np.float64) ** -0.7)[None]) @ b
+        w = w / np.sqrt((w ** 2).mean()) + 0.25 * rs.randn(cout, fan)
     else:
         raise ValueError(family)
     w = w / np.sqrt((w ** 2).mean()) * np.sqrt(2.0 / fan)

@@ -11,6 +11,7 @@ import numpy as np  # noqa: E402
 
 import _oracle as orc  # noqa: E402
 import _synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _exp  # noqa: E401,E402,F401  (experiments build of the library)
 import caffe_rtpose_amd as r  # noqa: E402
 
 ap = argparse.ArgumentParser()

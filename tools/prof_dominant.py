@@ -4,6 +4,7 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _exp  # noqa: E401,E402,F401  (experiments build of the library)
 import caffe_rtpose_amd as r  # noqa: E402
 prec = {"fp32": r.PREC_FP32, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}.get(sys.argv[1] if len(sys.argv) > 1 else "fp16", r.PREC_FP16)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200

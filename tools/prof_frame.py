@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _exp  # noqa: E401,E402,F401  (experiments build of the library)
 import caffe_rtpose_amd as r  # noqa: E402
 prec = r.PREC_FP32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else r.PREC_FP16
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -2,6 +2,7 @@ import os, sys, threading
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _exp  # noqa: E401,E402,F401  (experiments build of the library)
 import caffe_rtpose_amd as r
 kw = dict(net_w=320, net_h=176, num_scales=2, scale_gap=0.25, disp_w=640, disp_h=360)
 A = r.Engine(r.Config(frames_in_flight=1, **kw))
