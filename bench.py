@@ -415,6 +415,7 @@ def main():
     ap.add_argument("--model", default="coco", choices=["coco", "mpi"], help="coco = BASELINE configs[1..3] (656x368); mpi = configs[4] (15 parts, 496x368)")
     ap.add_argument("--exec", dest="exec_mode", default="graph", choices=["graph", "eager"])
     ap.add_argument("--comm", default="auto", choices=["auto", "nccl", "gloo"], help="process group for the barrier / reductions around the timed region (N > 1)")
+    ap.add_argument("--devices", default=None, help="device of every rank, e.g. 0,0: lets N ranks share one GPU (a test hook like rtpose.bin --devices; default: rank i uses device LOCAL_RANK)")
     ap.add_argument("--broadcast_weights", action="store_true", help="N > 1: rank 0's packed weight arena is broadcast to the other ranks (rtp_weight_blob_export / import) "
                     "instead of every rank keeping the copy it packed itself; one-time, outside the timed region")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -437,6 +438,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.devices:
+        devs = [int(d) for d in args.devices.split(",")]
+        if len(devs) != world:
+            sys.exit(f"bench.py: --devices names {len(devs)} devices for {world} rank(s)")
+        local = devs[rank]
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); using WORLD_SIZE", file=sys.stderr)

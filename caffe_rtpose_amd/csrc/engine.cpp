@@ -143,6 +143,11 @@ struct Ctx {
   float* host_in = nullptr;   // pinned staging
   float* lowres = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};  // around the conv stack
+  // Input staging (H2D of a frame, device pre-processing, or the copy of a resident input) runs on its own stream, so that a frame's copy
+  // is under way while earlier batches compute and the conv queue never holds a barrier that waits for PCIe; ev_in = staged input complete
+  hipStream_t in_stream = nullptr;
+  hipEvent_t ev_in = nullptr;
+  bool in_pending = false;
   std::vector<Slot> slot;
   int filled = 0;        // frames staged in the open batch
   bool launched = false;
@@ -208,6 +213,11 @@ struct rtp_engine {
   bool use_graph = true;
   bool split_fp8 = true;    // RTP_SPLIT_FP8=0: split layers run three fp16 passes everywhere
   bool graph_post = false;  // RTP_GRAPH_POST=1: also capture the per-frame post-processing chains + D2H into the batch graph
+  // 0 (default) = a batch's inputs are staged on its conv stream; 1 = on a stream of their own (created after all others), 2 = ... of high
+  // priority.  Measured (profiles/r04_input_staging.txt, host u8 frames, 7 in flight): 0: 1045 frames/s, 1: 880-890, 2: 880-990 — the
+  // runtime multiplexes streams onto 4 hardware queues, and a staging stream's barrier (kernel behind a PCIe copy) then blocks whichever
+  // conv / post-processing stream shares its queue.  Experiments build only (RTP_IN_STREAM).
+  int in_stream_mode = 0;
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
   std::string split_rules;
   int nctx_full = 1;            // batch contexts of the configured pipeline (a calibration trial runs with one)
@@ -1250,6 +1260,13 @@ int capture_batch(rtp_engine* e, Ctx& cx, int nframes, hipGraphExec_t* out) {
 
 int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize = false) {
   int rc;
+  if (cx.in_pending) {   // the batch's inputs were staged on the staging stream: the conv stream starts when the last of them is complete
+    if (cx.in_stream != cx.stream) {
+      HIPCHK(e, hipEventRecord(cx.ev_in, cx.in_stream));
+      HIPCHK(e, hipStreamWaitEvent(cx.stream, cx.ev_in, 0));
+    }
+    cx.in_pending = false;
+  }
   static const char* diag = RTP_EXP_ENV("RTP_DIAG_SKIP_POST");
   static const char* unf = RTP_EXP_ENV("RTP_POST_UNFUSED");
   // (a timing pass launches eagerly: its event pairs sit between the launches)
@@ -1378,6 +1395,8 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
 
 void free_ctx(Ctx& cx) {
   if (cx.stream) (void)hipStreamSynchronize(cx.stream);
+  if (cx.in_stream && cx.in_stream != cx.stream) { (void)hipStreamSynchronize(cx.in_stream); (void)hipStreamDestroy(cx.in_stream); }
+  if (cx.ev_in) (void)hipEventDestroy(cx.ev_in);
   for (Slot& sl : cx.slot) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     void* dptrs[] = {sl.resized, sl.peaks, sl.strip_count, sl.strip_list, sl.cand_score, sl.cand_ij, sl.cand_count, sl.cand_blk, sl.conn, sl.conn_score,
@@ -1475,7 +1494,7 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
   const size_t fbytes = (size_t)w * h * 3;
   if (fbytes > sl.frame_cap) {   // first frame of this slot (or a larger one): rare, and hipFree synchronises the device
     SYNC_GUARD;
-    HIPCHK(e, hipStreamSynchronize(cx.stream));
+    HIPCHK(e, hipStreamSynchronize(cx.in_stream));
     if (sl.frame_dev) (void)hipFree(sl.frame_dev);
     if (sl.frame_host) (void)hipHostFree(sl.frame_host);
     sl.frame_dev = nullptr; sl.frame_host = nullptr; sl.frame_cap = 0;
@@ -1488,9 +1507,10 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
   if (frame_scale) *frame_scale = (float)s;
   memcpy(sl.frame_host, bgr, fbytes);
   float* dst = cx.input + (size_t)sj * e->N * 3 * e->cfg.net_h * e->cfg.net_w;
-  HIPCHK(e, hipMemcpyAsync(sl.frame_dev, sl.frame_host, fbytes, hipMemcpyHostToDevice, cx.stream));
-  HIPCHK(e, launch_warp(sl.frame_dev, w, h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
-  HIPCHK(e, launch_area_pad(sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.stream));
+  HIPCHK(e, hipMemcpyAsync(sl.frame_dev, sl.frame_host, fbytes, hipMemcpyHostToDevice, cx.in_stream));
+  HIPCHK(e, launch_warp(sl.frame_dev, w, h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.in_stream));
+  HIPCHK(e, launch_area_pad(sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.in_stream));
+  cx.in_pending = true;
   return RTP_OK;
 }
 
@@ -1517,6 +1537,17 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
   e->ctx.resize(nctx);
   for (auto& c : e->ctx)
     if ((rc = alloc_ctx(e, c))) return rc;
+  // staging streams LAST: the runtime deals its hardware queues to streams round-robin in creation order, and the arrangement of the
+  // conv / post-processing streams is the measured optimum
+  for (auto& c : e->ctx) {
+    if (e->in_stream_mode == 0) c.in_stream = c.stream;
+    else if (e->in_stream_mode == 2) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      HIPCHK(e, hipStreamCreateWithPriority(&c.in_stream, hipStreamNonBlocking, greatest));
+    } else HIPCHK(e, hipStreamCreateWithFlags(&c.in_stream, hipStreamNonBlocking));
+    HIPCHK(e, hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
+  }
   {
     Ctx& cx = e->ctx[0];
     const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
@@ -1692,6 +1723,8 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     e->split_fp8 = !(f8 && f8[0] == '0');
     const char* gp = RTP_EXP_ENV("RTP_GRAPH_POST");
     e->graph_post = gp && gp[0] == '1';
+    const char* im = RTP_EXP_ENV("RTP_IN_STREAM");   // experiments: 0 = stage inputs on the conv stream, 1 = own stream, 2 = own high-priority stream
+    if (im) e->in_stream_mode = atoi(im);
   }
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
 
@@ -1814,7 +1847,8 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
     e->open_ctx = -1;
     return launch_batch(e, cx, 1, d_in);
   }
-  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, d_in, bytes, hipMemcpyDeviceToDevice, cx.stream));
+  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, d_in, bytes, hipMemcpyDeviceToDevice, cx.in_stream));
+  cx.in_pending = true;
   cx.slot[sj].has_disp = false;
   return commit_slot(e, ci, sj, tag);
 }
@@ -1827,7 +1861,8 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   memcpy((char*)cx.host_in + sj * bytes, h_in, bytes);
-  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, cx.stream));
+  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, cx.in_stream));
+  cx.in_pending = true;
   cx.slot[sj].has_disp = false;
   return commit_slot(e, ci, sj, tag);
 }
@@ -1849,7 +1884,8 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint
     rc = rtp_preprocess_frame(bgr, w, h, e->cfg.disp_w, e->cfg.disp_h, e->cfg.net_w, e->cfg.net_h, e->N, e->start_scale, e->scale_gap,
                               hin, nullptr, frame_scale);
     if (rc) return fail(e, rc, "pre-processing failed (a scale does not fit the net resolution?)");
-    HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, hin, bytes, hipMemcpyHostToDevice, cx.stream));
+    HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, hin, bytes, hipMemcpyHostToDevice, cx.in_stream));
+    cx.in_pending = true;
   }
   return commit_slot(e, ci, sj, tag);
 }
@@ -1872,7 +1908,8 @@ int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, 
   if (!e->gpu_prep_ok) return fail(e, RTP_EINVAL, "device pre-processing unavailable for this configuration (a level would be enlarged)");
   Ctx& cx = e->ctx[0];
   if ((rc = enqueue_preprocess(e, cx, 0, bgr, w, h, frame_scale))) return rc;
-  HIPCHK(e, hipStreamSynchronize(cx.stream));
+  cx.in_pending = false;
+  HIPCHK(e, hipStreamSynchronize(cx.in_stream));
   if (net_input) HIPCHK(e, hipMemcpy(net_input, cx.input, (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
   if (display_bgr) HIPCHK(e, hipMemcpy(display_bgr, cx.slot[0].disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3, hipMemcpyDeviceToHost));
   return RTP_OK;

@@ -48,3 +48,24 @@ def test_rccl_failure_falls_back_to_gloo_and_says_so():
 def test_auto_comm_is_gloo_without_a_gpu():
     out = _run(["--gpus", "2"])[0]
     assert out["comm_backend"] == "gloo" and out["comm_note"] is None
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_with_weight_broadcast():
+    """The N > 1 path of bench.py with REAL engines, as far as one GPU can show it: two ranks under torch.distributed.run, both on
+    device 0 (--devices 0,0), gloo process group next to the engines' HIP runtime, rank 0's packed weight blob (arena + Caffe-layout
+    floats) broadcast to rank 1 and imported, barrier + MAX-reduce around the timed region, one line from rank 0 with both ranks' rates."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--comm", "gloo", "--broadcast_weights", "--steps", "60", "--warmup", "10",
+                        "--min_seconds", "0.5", "--no_cpu_baseline", "--no_sub_results", "--no_parity"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["comm_backend"] == "gloo" and out["scaling"] == "weak"
+    assert len(out["per_rank_frames_per_s"]) == 2 and min(out["per_rank_frames_per_s"]) > 100
+    assert abs(out["value"] - sum(out["per_rank_frames_per_s"])) < 0.25 * out["value"]        # whole-job aggregate (the slowest rank's clock)
+    assert out["weight_broadcast"]["bytes"] > 250e6 and 0.05 < out["roofline"]["frac"] < 1
