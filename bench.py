@@ -426,7 +426,7 @@ def main():
     if args.batch_frames is None:
         args.batch_frames = 5 if args.model == "mpi" else (2 if args.num_scales == 1 else 1)
     if args.in_flight is None:
-        table = {("mpi", 5): 10, ("coco", 2): 7, ("coco", 1): 7 if args.num_scales == 1 else 3}
+        table = {("mpi", 5): 10, ("coco", 2): 7 if args.num_scales == 1 else 6, ("coco", 1): 7 if args.num_scales == 1 else 3}   # measured optima (profiles/r03_in_flight.txt)
         args.in_flight = max(table.get((args.model, args.batch_frames), 2 * args.batch_frames), args.batch_frames)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -123,6 +123,11 @@ struct Slot {
   int* num_people = nullptr;
   float* host_out = nullptr;  // pinned: [1 int as float slot][joints]
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // post start, resize, nms, connect, results on host
+  // deferred pre-processing (rtp_engine::prep_defer): the frame's H2D copy runs on the engine's copy stream; its warp / area kernels are
+  // enqueued on the batch's conv stream once the copy has COMPLETED (polled at the next API call; forced, with a stream wait, at launch)
+  hipEvent_t ev_copy = nullptr;
+  bool copy_pending = false;
+  int pend_w = 0, pend_h = 0;
   unsigned char* frame_dev = nullptr;   // raw u8 frame (device) for rtp_submit_frame
   unsigned char* frame_host = nullptr;  // pinned staging of the raw frame
   size_t frame_cap = 0;
@@ -218,6 +223,12 @@ struct rtp_engine {
   // runtime multiplexes streams onto 4 hardware queues, and a staging stream's barrier (kernel behind a PCIe copy) then blocks whichever
   // conv / post-processing stream shares its queue.  Experiments build only (RTP_IN_STREAM).
   int in_stream_mode = 0;
+  // 1 = deferred pre-processing: no kernel of a compute queue ever waits for a PCIe copy.  With the copy and the kernels on one stream
+  // (0) the barrier packet in front of the warp kernel holds that stream's HARDWARE queue — shared with another context's conv stack or
+  // post-processing chain — for the duration of the copy.
+  int prep_defer = 0;
+  hipStream_t copy_stream = nullptr;   // H2D copies only (created after every other stream)
+  std::deque<int> pending_launch;      // full batches whose last frame's copy was still in flight when it was committed (launched by pump())
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
   std::string split_rules;
   int nctx_full = 1;            // batch contexts of the configured pipeline (a calibration trial runs with one)
@@ -1258,8 +1269,10 @@ int capture_batch(rtp_engine* e, Ctx& cx, int nframes, hipGraphExec_t* out) {
   return RTP_OK;
 }
 
+int flush_prep(rtp_engine* e, Ctx& cx, bool force);
 int launch_batch(rtp_engine* e, Ctx& cx, int nframes, const float* input_dev, bool materialize = false) {
   int rc;
+  if (e->prep_defer && (rc = flush_prep(e, cx, true))) return rc;
   if (cx.in_pending) {   // the batch's inputs were staged on the staging stream: the conv stream starts when the last of them is complete
     if (cx.in_stream != cx.stream) {
       HIPCHK(e, hipEventRecord(cx.ev_in, cx.in_stream));
@@ -1406,6 +1419,7 @@ void free_ctx(Ctx& cx) {
     if (sl.render_host) (void)hipHostFree(sl.render_host);
     if (sl.host_out) (void)hipHostFree(sl.host_out);
     for (int i = 0; i < 5; ++i) if (sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
+    if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   for (hipGraphExec_t& g : cx.gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
@@ -1506,11 +1520,36 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
   const double s = rtp_display_fit_scale(w, h, e->cfg.disp_w, e->cfg.disp_h);
   if (frame_scale) *frame_scale = (float)s;
   memcpy(sl.frame_host, bgr, fbytes);
+  if (e->prep_defer) {   // copy now, kernels when the copy is done (flush_prep)
+    if (!sl.ev_copy) HIPCHK(e, hipEventCreateWithFlags(&sl.ev_copy, hipEventDisableTiming));
+    HIPCHK(e, hipMemcpyAsync(sl.frame_dev, sl.frame_host, fbytes, hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(e, hipEventRecord(sl.ev_copy, e->copy_stream));
+    sl.copy_pending = true;
+    sl.pend_w = w; sl.pend_h = h;
+    return RTP_OK;
+  }
   float* dst = cx.input + (size_t)sj * e->N * 3 * e->cfg.net_h * e->cfg.net_w;
   HIPCHK(e, hipMemcpyAsync(sl.frame_dev, sl.frame_host, fbytes, hipMemcpyHostToDevice, cx.in_stream));
   HIPCHK(e, launch_warp(sl.frame_dev, w, h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.in_stream));
   HIPCHK(e, launch_area_pad(sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.in_stream));
   cx.in_pending = true;
+  return RTP_OK;
+}
+
+// Deferred pre-processing: enqueue the warp / area kernels of every frame of `cx` whose H2D copy has completed (force: of every
+// pending frame, behind a stream wait on its copy — the batch is about to be launched).
+int flush_prep(rtp_engine* e, Ctx& cx, bool force) {
+  for (size_t sj = 0; sj < cx.slot.size(); ++sj) {
+    Slot& sl = cx.slot[sj];
+    if (!sl.copy_pending) continue;
+    if (force) HIPCHK(e, hipStreamWaitEvent(cx.stream, sl.ev_copy, 0));
+    else if (hipEventQuery(sl.ev_copy) != hipSuccess) continue;
+    const double s = rtp_display_fit_scale(sl.pend_w, sl.pend_h, e->cfg.disp_w, e->cfg.disp_h);
+    float* dst = cx.input + sj * (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
+    HIPCHK(e, launch_warp(sl.frame_dev, sl.pend_w, sl.pend_h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
+    HIPCHK(e, launch_area_pad(sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.stream));
+    sl.copy_pending = false;
+  }
   return RTP_OK;
 }
 
@@ -1548,6 +1587,7 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
     } else HIPCHK(e, hipStreamCreateWithFlags(&c.in_stream, hipStreamNonBlocking));
     HIPCHK(e, hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
   }
+  if (e->prep_defer && !e->copy_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   {
     Ctx& cx = e->ctx[0];
     const size_t in_floats = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
@@ -1578,6 +1618,7 @@ void drop_plan(rtp_engine* e) {
   e->tensors.clear(); e->blob_tensor.clear(); e->blob_dims.clear(); e->convs.clear(); e->steps.clear(); e->pools.clear();
   e->open_ctx = -1;
   e->fifo.clear();
+  e->pending_launch.clear();
 }
 
 // Re-plan an idle engine for another precision mode / split set (load-time calibration).  light = one context, no graph capture.
@@ -1614,13 +1655,35 @@ int launch_open(rtp_engine* e) {
   if (cx.filled == 0) return RTP_OK;
   return launch_batch(e, cx, cx.filled, cx.input);
 }
+// Deferred pre-processing: launch the full batches that were waiting for their last frame's copy, oldest first; force = wait for the copies
+// on the stream instead of polling (somebody needs the batch now).
+int pump(rtp_engine* e, bool force) {
+  while (!e->pending_launch.empty()) {
+    Ctx& cx = e->ctx[e->pending_launch.front()];
+    if (!force)
+      for (Slot& sl : cx.slot)
+        if (sl.copy_pending && hipEventQuery(sl.ev_copy) != hipSuccess) return RTP_OK;   // not yet: the next API call looks again
+    e->pending_launch.pop_front();
+    const int rc = launch_batch(e, cx, cx.filled, cx.input);   // (flush_prep inside: every copy is done, or waited for on the stream)
+    if (rc) return rc;
+  }
+  return RTP_OK;
+}
 int commit_slot(rtp_engine* e, int ci, int sj, uint64_t tag) {
   Ctx& cx = e->ctx[ci];
   cx.slot[sj].tag = tag;
   cx.slot[sj].busy = true;
   cx.filled = sj + 1;
   e->fifo.push_back(ci * 64 + sj);
-  if (cx.filled == e->B) return launch_open(e);
+  if (cx.filled == e->B) {
+    if (e->prep_defer && e->B > 1 && cx.slot[sj].copy_pending) {   // the frame that completes the batch was copied a moment ago: launch at the next call
+      e->open_ctx = -1;
+      e->pending_launch.push_back(ci);
+      return RTP_OK;
+    }
+    if (e->prep_defer) { const int rc = pump(e, true); if (rc) return rc; }   // keep the launch order
+    return launch_open(e);
+  }
   return RTP_OK;
 }
 
@@ -1665,6 +1728,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   if (e->dchmap) (void)hipFree(e->dchmap);
   for (hipEvent_t ev : e->tev) if (ev) (void)hipEventDestroy(ev);
   if (e->prep_tables) (void)hipFree(e->prep_tables);
+  if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
   for (void* p : e->user_bufs) if (p) (void)hipFree(p);
   delete e;
 }
@@ -1725,6 +1789,8 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     e->graph_post = gp && gp[0] == '1';
     const char* im = RTP_EXP_ENV("RTP_IN_STREAM");   // experiments: 0 = stage inputs on the conv stream, 1 = own stream, 2 = own high-priority stream
     if (im) e->in_stream_mode = atoi(im);
+    const char* pd = RTP_EXP_ENV("RTP_PREP_DEFER");   // experiments: 0 / 1 = pre-processing kernels right behind the copy / once the copy has completed
+    if (pd) e->prep_defer = atoi(pd);
   }
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
 
@@ -1835,6 +1901,7 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if (!e || !d_in) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
+  if (e->prep_defer && (rc = pump(e, false))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
@@ -1857,6 +1924,7 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   if (!e || !h_in) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
+  if (e->prep_defer && (rc = pump(e, false))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
@@ -1873,8 +1941,10 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint
   if (!e || !bgr || w < 1 || h < 1) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
+  if (e->prep_defer && (rc = pump(e, false))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
+  if (e->prep_defer && (rc = flush_prep(e, cx, false))) return rc;   // an earlier frame of this batch whose copy is done by now
   cx.slot[sj].has_disp = e->gpu_prep_ok;
   if (e->gpu_prep_ok) {
     if ((rc = enqueue_preprocess(e, cx, sj, bgr, w, h, frame_scale))) return rc;
@@ -1895,6 +1965,7 @@ int rtp_flush(rtp_engine* e) {
   if (!e) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
+  if (e->prep_defer && (rc = pump(e, true))) return rc;
   return launch_open(e);
 }
 
@@ -1908,8 +1979,9 @@ int rtp_debug_preprocess(rtp_engine* e, const unsigned char* bgr, int w, int h, 
   if (!e->gpu_prep_ok) return fail(e, RTP_EINVAL, "device pre-processing unavailable for this configuration (a level would be enlarged)");
   Ctx& cx = e->ctx[0];
   if ((rc = enqueue_preprocess(e, cx, 0, bgr, w, h, frame_scale))) return rc;
+  if (e->prep_defer && (rc = flush_prep(e, cx, true))) return rc;
   cx.in_pending = false;
-  HIPCHK(e, hipStreamSynchronize(cx.in_stream));
+  HIPCHK(e, hipStreamSynchronize(e->prep_defer ? cx.stream : cx.in_stream));
   if (net_input) HIPCHK(e, hipMemcpy(net_input, cx.input, (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float), hipMemcpyDeviceToHost));
   if (display_bgr) HIPCHK(e, hipMemcpy(display_bgr, cx.slot[0].disp_dev, (size_t)e->cfg.disp_w * e->cfg.disp_h * 3, hipMemcpyDeviceToHost));
   return RTP_OK;
@@ -1951,6 +2023,10 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   const int ci = e->fifo.front() / 64, sj = e->fifo.front() % 64;
   Ctx& cx = e->ctx[ci];
   Slot& sl = cx.slot[sj];
+  if (e->prep_defer) {
+    if ((rc = pump(e, !cx.launched && std::find(e->pending_launch.begin(), e->pending_launch.end(), ci) != e->pending_launch.end()))) return rc;
+    if (e->open_ctx >= 0 && e->open_ctx != ci && (rc = flush_prep(e, e->ctx[e->open_ctx], false))) return rc;
+  }
   if (!cx.launched && (rc = launch_open(e))) return rc;  // the oldest frame sits in a partial batch
   HIPCHK(e, hipEventSynchronize(cx.graph_run ? cx.gev[1] : sl.ev[4]));
   e->fifo.pop_front();

@@ -773,3 +773,29 @@ def test_weight_blob_and_peer_copy_reproduce_the_source_engine():
         other.copy_weights_from(src)
     for e in (src, a, b, other):
         e.close()
+
+
+def test_deferred_preprocessing_and_staging_streams_do_not_change_results():
+    """rtp_submit_frame variants of the experiments build that only change WHEN / WHERE a frame's H2D copy and pre-processing kernels are
+    issued (RTP_PREP_DEFER=1: the kernels are enqueued once the copy has completed and a full batch is launched at the next call;
+    RTP_IN_STREAM=1 / 2: a staging stream): the joints of 23 pipelined frames — full batches, the trailing partial batch, batches of 1
+    and 2 — hash identically to the production library's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "ab_frames.py")
+    exp = os.path.join(root, "caffe_rtpose_amd", "librtpose_mi355x_exp.so")
+
+    def run(args, **env):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, tool] + args, env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l.startswith("frames")][-1].split(": ")[1]
+
+    for args in (["2", "7"], ["1", "3"], ["2", "2"]):
+        base = run(args)
+        assert run(args, RTP_LIB=exp, RTP_PREP_DEFER="1") == base, args
+        assert run(args, RTP_LIB=exp, RTP_PREP_DEFER="0") == base, args
+    assert run(["2", "7"], RTP_LIB=exp, RTP_IN_STREAM="1") == run(["2", "7"])
+    assert run(["2", "7"], RTP_LIB=exp, RTP_IN_STREAM="2", RTP_PREP_DEFER="1") == run(["2", "7"])
