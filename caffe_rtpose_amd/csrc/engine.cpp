@@ -223,10 +223,11 @@ struct rtp_engine {
   // runtime multiplexes streams onto 4 hardware queues, and a staging stream's barrier (kernel behind a PCIe copy) then blocks whichever
   // conv / post-processing stream shares its queue.  Experiments build only (RTP_IN_STREAM).
   int in_stream_mode = 0;
-  // 1 = deferred pre-processing: no kernel of a compute queue ever waits for a PCIe copy.  With the copy and the kernels on one stream
-  // (0) the barrier packet in front of the warp kernel holds that stream's HARDWARE queue — shared with another context's conv stack or
-  // post-processing chain — for the duration of the copy.
-  int prep_defer = 0;
+  // 1 (default) = deferred pre-processing: no kernel of a compute queue ever waits for a PCIe copy.  With the copy and the kernels on one
+  // stream (0, round 3) the barrier packet in front of the warp kernel holds that stream's HARDWARE queue — shared with another context's
+  // conv stack or post-processing chain — for the duration of the copy.  Measured (profiles/r04_input_staging.txt): COCO 1028-1032 ->
+  // 1036-1039 frames/s, MPI (batches of 5) 1211 -> 1271; bit-identical joints (GPU test).
+  int prep_defer = 1;
   hipStream_t copy_stream = nullptr;   // H2D copies only (created after every other stream)
   std::deque<int> pending_launch;      // full batches whose last frame's copy was still in flight when it was committed (launched by pump())
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
@@ -1544,6 +1545,7 @@ int flush_prep(rtp_engine* e, Ctx& cx, bool force) {
     if (!sl.copy_pending) continue;
     if (force) HIPCHK(e, hipStreamWaitEvent(cx.stream, sl.ev_copy, 0));
     else if (hipEventQuery(sl.ev_copy) != hipSuccess) continue;
+    if (sl.pend_w == 0) { sl.copy_pending = false; continue; }   // rtp_submit: the copy WAS the staging (net input already pre-processed)
     const double s = rtp_display_fit_scale(sl.pend_w, sl.pend_h, e->cfg.disp_w, e->cfg.disp_h);
     float* dst = cx.input + sj * (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w;
     HIPCHK(e, launch_warp(sl.frame_dev, sl.pend_w, sl.pend_h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
@@ -1929,8 +1931,17 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   memcpy((char*)cx.host_in + sj * bytes, h_in, bytes);
-  HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, cx.in_stream));
-  cx.in_pending = true;
+  if (e->prep_defer) {   // the copy on the copy-only stream; the conv stream learns about it when it has completed (flush_prep / pump)
+    Slot& sl = cx.slot[sj];
+    if (!sl.ev_copy) HIPCHK(e, hipEventCreateWithFlags(&sl.ev_copy, hipEventDisableTiming));
+    HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(e, hipEventRecord(sl.ev_copy, e->copy_stream));
+    sl.copy_pending = true;
+    sl.pend_w = sl.pend_h = 0;
+  } else {
+    HIPCHK(e, hipMemcpyAsync((char*)cx.input + sj * bytes, (char*)cx.host_in + sj * bytes, bytes, hipMemcpyHostToDevice, cx.in_stream));
+    cx.in_pending = true;
+  }
   cx.slot[sj].has_disp = false;
   return commit_slot(e, ci, sj, tag);
 }

@@ -716,6 +716,7 @@ def test_ring_kernel_variants_are_bit_identical():
     assert strip(run(RTP_LIB=exp)) == strip(base)                                # the experiments build without knobs = the production bits
     assert strip(run(RTP_LIB=exp, RTP_RING_ILV="1")) == strip(base)
     assert strip(run(RTP_LIB=exp, RTP_HALO_SHARED="0")) == strip(base)
+    assert strip(run(RTP_LIB=exp, RTP_PREP_DEFER="0")) == strip(base)             # rtp_submit's copy on the conv stream (round 3) vs on the copy-only stream (default)
     assert strip(run(RTP_RING_VAR="12", RTP_DIAG_SKIP_POST="2")) == strip(base)  # the production library does not know these names
 
 
