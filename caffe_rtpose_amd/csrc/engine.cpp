@@ -223,11 +223,13 @@ struct rtp_engine {
   // runtime multiplexes streams onto 4 hardware queues, and a staging stream's barrier (kernel behind a PCIe copy) then blocks whichever
   // conv / post-processing stream shares its queue.  Experiments build only (RTP_IN_STREAM).
   int in_stream_mode = 0;
-  // 1 (default) = deferred pre-processing: no kernel of a compute queue ever waits for a PCIe copy.  With the copy and the kernels on one
-  // stream (0, round 3) the barrier packet in front of the warp kernel holds that stream's HARDWARE queue — shared with another context's
-  // conv stack or post-processing chain — for the duration of the copy.  Measured (profiles/r04_input_staging.txt): COCO 1028-1032 ->
-  // 1036-1039 frames/s, MPI (batches of 5) 1211 -> 1271; bit-identical joints (GPU test).
-  int prep_defer = 1;
+  // 1 = deferred pre-processing (experiments build, RTP_PREP_DEFER): a frame's copy goes to a copy-only stream, its kernels are enqueued on
+  // the conv stream once the copy has COMPLETED (polled at the next API call), a full batch whose last frame was just copied is launched at
+  // the next call — so that no kernel of a compute queue sits behind a barrier that waits for PCIe.  Bit-identical (GPU test), and not
+  // adopted: what it gains depends on WHEN the caller makes its next call.  tools/bench_input.py: COCO +0.7 %, MPI (batches of 5) +5 %;
+  // inside bench.py's loop (a collect right behind the submit that completes a batch): COCO -5 %, MPI +-0; waiting for the copy on the
+  // host instead: -23 % (hipEventSynchronize ~0.3 ms per call).  profiles/r04_input_staging.txt.
+  int prep_defer = 0;
   hipStream_t copy_stream = nullptr;   // H2D copies only (created after every other stream)
   std::deque<int> pending_launch;      // full batches whose last frame's copy was still in flight when it was committed (launched by pump())
   int mode = 0;  // rtp_config.precision (RTP_PREC_*); `prec` below selects the kernels' element type (0 fp16, 1 fp32)
@@ -1657,14 +1659,21 @@ int launch_open(rtp_engine* e) {
   if (cx.filled == 0) return RTP_OK;
   return launch_batch(e, cx, cx.filled, cx.input);
 }
-// Deferred pre-processing: launch the full batches that were waiting for their last frame's copy, oldest first; force = wait for the copies
-// on the stream instead of polling (somebody needs the batch now).
-int pump(rtp_engine* e, bool force) {
+// Deferred pre-processing: launch the full batches that were waiting for their last frame's copy, oldest first.
+//   PUMP_POLL   launch what is ready (hipEventQuery), leave the rest for the next call            — rtp_submit*
+//   PUMP_HOST   wait for the copies ON THE HOST (<= one PCIe copy, ~55 us), then launch             — rtp_collect, which is about to block for a
+//               whole frame anyway: a batch must not sit un-launched behind that wait
+//   PUMP_STREAM launch now, the conv stream waits for the copies                                   — somebody needs this very batch (rtp_flush)
+enum { PUMP_POLL = 0, PUMP_HOST = 1, PUMP_STREAM = 2 };
+int pump(rtp_engine* e, int mode) {
   while (!e->pending_launch.empty()) {
     Ctx& cx = e->ctx[e->pending_launch.front()];
-    if (!force)
-      for (Slot& sl : cx.slot)
-        if (sl.copy_pending && hipEventQuery(sl.ev_copy) != hipSuccess) return RTP_OK;   // not yet: the next API call looks again
+    if (mode != PUMP_STREAM)
+      for (Slot& sl : cx.slot) {
+        if (!sl.copy_pending) continue;
+        if (mode == PUMP_HOST) HIPCHK(e, hipEventSynchronize(sl.ev_copy));
+        else if (hipEventQuery(sl.ev_copy) != hipSuccess) return RTP_OK;   // not yet: the next API call looks again
+      }
     e->pending_launch.pop_front();
     const int rc = launch_batch(e, cx, cx.filled, cx.input);   // (flush_prep inside: every copy is done, or waited for on the stream)
     if (rc) return rc;
@@ -1683,7 +1692,7 @@ int commit_slot(rtp_engine* e, int ci, int sj, uint64_t tag) {
       e->pending_launch.push_back(ci);
       return RTP_OK;
     }
-    if (e->prep_defer) { const int rc = pump(e, true); if (rc) return rc; }   // keep the launch order
+    if (e->prep_defer) { const int rc = pump(e, PUMP_STREAM); if (rc) return rc; }   // keep the launch order
     return launch_open(e);
   }
   return RTP_OK;
@@ -1793,6 +1802,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     if (im) e->in_stream_mode = atoi(im);
     const char* pd = RTP_EXP_ENV("RTP_PREP_DEFER");   // experiments: 0 / 1 = pre-processing kernels right behind the copy / once the copy has completed
     if (pd) e->prep_defer = atoi(pd);
+    if (e->B == 1) e->prep_defer = 0;   // a batch of one frame is launched by the submit that stages it: nothing to defer, the copy stays on the conv stream
   }
   auto bail = [&](int rc) { g_create_error = e->err; rtp_engine_destroy(e); return rc; };
 
@@ -1903,7 +1913,7 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if (!e || !d_in) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
-  if (e->prep_defer && (rc = pump(e, false))) return rc;
+  if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
@@ -1926,7 +1936,7 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   if (!e || !h_in) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
-  if (e->prep_defer && (rc = pump(e, false))) return rc;
+  if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
@@ -1952,7 +1962,7 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint
   if (!e || !bgr || w < 1 || h < 1) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
-  if (e->prep_defer && (rc = pump(e, false))) return rc;
+  if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
   if (e->prep_defer && (rc = flush_prep(e, cx, false))) return rc;   // an earlier frame of this batch whose copy is done by now
@@ -1976,7 +1986,7 @@ int rtp_flush(rtp_engine* e) {
   if (!e) return RTP_EINVAL;
   int rc;
   if ((rc = use_device(e))) return rc;
-  if (e->prep_defer && (rc = pump(e, true))) return rc;
+  if (e->prep_defer && (rc = pump(e, PUMP_STREAM))) return rc;
   return launch_open(e);
 }
 
@@ -2035,7 +2045,8 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   Ctx& cx = e->ctx[ci];
   Slot& sl = cx.slot[sj];
   if (e->prep_defer) {
-    if ((rc = pump(e, !cx.launched && std::find(e->pending_launch.begin(), e->pending_launch.end(), ci) != e->pending_launch.end()))) return rc;
+    if ((rc = pump(e, PUMP_STREAM))) return rc;   // nothing stays un-launched while this call blocks for a frame (a host-side wait for the copy
+                                                  // was measured: hipEventSynchronize costs ~0.3 ms per call here, 1010 -> 777 frames/s)
     if (e->open_ctx >= 0 && e->open_ctx != ci && (rc = flush_prep(e, e->ctx[e->open_ctx], false))) return rc;
   }
   if (!cx.launched && (rc = launch_open(e))) return rc;  // the oldest frame sits in a partial batch
