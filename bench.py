@@ -129,7 +129,7 @@ def cpu_baseline(eng, num_scales, model="coco", frames=3, oracle=None):
     import torch
     import _oracle as orc
     mid, W, H, parts, max_peaks, thr, gflop = MODELS[model]
-    net, fr = oracle if oracle is not None else oracle_frames(eng, num_scales, model, frames)
+    _, fr = oracle if oracle is not None else oracle_frames(eng, num_scales, model, frames)
     frames = len(fr) - 1
     tc = tp = 0.0
     for f, (x, low, t_conv) in enumerate(fr):
@@ -182,7 +182,7 @@ def parity_report(eng, fr, model, num_scales, scale_gap, structured=True):
     import _oracle as orc
     import _parity
     import _explain
-    mid, W, H, parts, max_peaks, thr, _ = MODELS[model]
+    mid, W, H, parts, max_peaks, _, _ = MODELS[model]
     th = eng.get_thresholds()
     reps, exps, map_err, post_exact, dev = [], [], 0.0, True, None
     for x, ref, _ in fr:
@@ -665,7 +665,7 @@ def sub_results(args, r, eng, make_engine, device_frames, host_frames, measure, 
     import _synth
     res = {}
     short = dict(steps=50, warmup=10, min_seconds=1.0)
-    mid, W, H, _, _, _, gflop = MODELS[args.model]
+    gflop = MODELS[args.model][6]
     # (1) the other input mode of the headline engine: net inputs already resident in HBM (no PCIe, no pre-processing) — or, when the
     #     headline was asked for with --input resident, BASELINE configs[1] as written
     try:
@@ -690,7 +690,7 @@ def sub_results(args, r, eng, make_engine, device_frames, host_frames, measure, 
         for name, low in cases:
             low = np.ascontiguousarray(low, np.float32)
             t = []
-            for it in range(6):
+            for _ in range(6):
                 _, _, n = eng.post_from_lowres(low)
                 t.append(eng.last_stage_ms())
             t = t[1:]

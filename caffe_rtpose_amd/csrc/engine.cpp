@@ -2806,10 +2806,18 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   std::vector<float> ref(low_floats * nframes), got(low_floats);
   auto run = [&](const float* x, float* out) { return rtp_forward_heatmaps(e, x, out); };
   const std::string base_rules = e->split_rules;
+  // a failure half way (a trial plan that does not fit the device, a HIP error) must not leave the caller with a one-context trial engine:
+  // put the plan it came with back (best effort) and report the original error
+  auto bail = [&](int code) {
+    const std::string msg = e->err;
+    (void)replan(e, RTP_PREC_MIXED, base_rules, false);
+    e->err = msg;
+    return code;
+  };
   // reference maps
-  if ((rc = replan(e, RTP_PREC_F16X3, base_rules, true))) return rc;
+  if ((rc = replan(e, RTP_PREC_F16X3, base_rules, true))) return bail(rc);
   for (int f = 0; f < nframes; ++f)
-    if ((rc = run(frames_host + (size_t)f * in_floats, ref.data() + (size_t)f * low_floats))) return rc;
+    if ((rc = run(frames_host + (size_t)f * in_floats, ref.data() + (size_t)f * low_floats))) return bail(rc);
   double norm = 0;
   for (float v : ref) norm = std::max(norm, (double)std::fabs(v));
   if (!(norm > 0) || !std::isfinite(norm)) {
@@ -2833,8 +2841,8 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   std::ostringstream rep;
   std::string rules = base_rules;
   double err = 0;
-  if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return rc;
-  if ((rc = measure(&err))) return rc;
+  if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return bail(rc);
+  if ((rc = measure(&err))) return bail(rc);
   if (err_before) *err_before = (float)err;
   rep << "target " << target << "; frames " << nframes << "; set \"" << rules << "\" err " << err;
   // the layer groups a rule can name: trunk blocks by their "convN_" prefix, stage 1, the refinement stages (from the MIXED plan's flags)
@@ -2864,8 +2872,8 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
     double best_err = 1e300;
     for (size_t g = 0; g < groups.size(); ++g) {
       double eg = 0;
-      if ((rc = replan(e, RTP_PREC_MIXED, rules + "," + groups[g], true))) return rc;
-      if ((rc = measure(&eg))) return rc;
+      if ((rc = replan(e, RTP_PREC_MIXED, rules + "," + groups[g], true))) return bail(rc);
+      if ((rc = measure(&eg))) return bail(rc);
       rep << "; try +" << groups[g] << " -> " << eg;
       if (eg < best_err) { best_err = eg; best = (int)g; }
     }
@@ -2878,13 +2886,13 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   // beyond +-112 or rounding errors beyond their range saturate; 3 mantissa bits).  Groups switch to fp16 correction passes (":x"),
   // ranked by what the switch gains alone, applied cumulatively until the target holds.
   if (err > target) {
-    if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return rc;
+    if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return bail(rc);
     std::vector<std::string> hg = open_groups(true);
     std::vector<std::pair<double, std::string>> gain;
     for (auto& g : hg) {
       double eg = 0;
-      if ((rc = replan(e, RTP_PREC_MIXED, rules + "," + g + ":x", true))) return rc;
-      if ((rc = measure(&eg))) return rc;
+      if ((rc = replan(e, RTP_PREC_MIXED, rules + "," + g + ":x", true))) return bail(rc);
+      if ((rc = measure(&eg))) return bail(rc);
       rep << "; try " << g << ":x -> " << eg;
       gain.push_back({eg, g});
     }
@@ -2892,8 +2900,8 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
     for (auto& ge : gain) {
       if (err <= target) break;
       rules += "," + ge.second + ":x";
-      if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return rc;
-      if ((rc = measure(&err))) return rc;
+      if ((rc = replan(e, RTP_PREC_MIXED, rules, true))) return bail(rc);
+      if ((rc = measure(&err))) return bail(rc);
       rep << "; switch " << ge.second << ":x -> " << err;
     }
   }
@@ -2903,8 +2911,8 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
     rep << "; err " << err << " > target with every group switched: falling back to RTP_PREC_F16X3";
     err = 0;
   }
-  if ((rc = replan(e, final_mode, rules, false))) return rc;
-  if (final_mode == RTP_PREC_MIXED && (rc = measure(&err))) return rc;
+  if ((rc = replan(e, final_mode, rules, false))) return bail(rc);
+  if (final_mode == RTP_PREC_MIXED && (rc = measure(&err))) return bail(rc);
   if (err_after) *err_after = (float)err;
   rep << "; final " << (final_mode == RTP_PREC_MIXED ? "mixed" : "f16x3") << " set \"" << rules << "\" err " << err;
   e->calib_report = rep.str();

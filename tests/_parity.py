@@ -114,7 +114,7 @@ def reclassify(rep, flags):
     rep["numeric_out_of_tol"] -= n
     rep["joints_structural"] += n
     rep["adjacent_pixel_flips"] = rep.get("adjacent_pixel_flips", 0) + n
-    for f, (p, xe, ye, xr, yr, dc) in zip(flags, rep["out_of_tol"]):
+    for f, (p, xe, ye, xr, yr, _dc) in zip(flags, rep["out_of_tol"]):
         if f:
             rep["structural"].append(("both", -1, p, xe, ye, 0.0, xr, yr))
     rep["out_of_tol"] = [o for f, o in zip(flags, rep["out_of_tol"]) if not f]

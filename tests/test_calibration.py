@@ -103,7 +103,7 @@ def test_calibration_at_engine_creation_and_argument_checks():
     x = _synth.random_frame(1, 176, 320, seed=3)
     assert _err(e, x, _oracle_maps(e, x)) <= 1e-3
     own = np.stack([_synth.random_frame(1, 176, 320, seed=s) for s in (5, 6)])     # the caller's own sample frames
-    rules, b, a = e.calibrate_precision(frames=own, target=0.7e-3)
+    rules, _before, a = e.calibrate_precision(frames=own, target=0.7e-3)
     assert a <= 0.7e-3 or rules == "@f16x3"
     e.submit(x, tag=9)
     with pytest.raises(r.RtpError):         # idle engines only

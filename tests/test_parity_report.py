@@ -139,7 +139,7 @@ def test_every_flip_of_a_sub_tolerance_perturbation_is_explained(model, seed, wh
     extremes of what a conv stack's rounding error can look like: people differ structurally, every joint that is the same peak stays
     inside the tolerance, and EVERY decision that differs (NMS compares, PAF samples against their threshold, sample coordinates at a
     rounding boundary, order inversions) has a reference-side margin below twice the measured deviation."""
-    W, H, parts, C, maxp = GEO[model]
+    W, H, _parts, C, maxp = GEO[model]
     thr = orc.default_thresholds(model)
     base = _synth.smooth_field(C, H // 8, W // 8, seed=seed, scale=1.0)[None]
     d = np.random.RandomState(100 + seed).uniform(-1, 1, base.shape).astype(np.float32) if white else _synth.smooth_field(C, H // 8, W // 8, seed=seed + 77)[None]
@@ -161,10 +161,10 @@ def test_a_difference_that_is_not_a_near_tie_is_not_explained():
     """Negative controls: (a) a peak that exists on one side only although the other side's maximum is nowhere near a tie, (b) a deviation
     well outside the tolerance, (c) structural differences without any flipped decision."""
     model = 0
-    W, H, parts, C, maxp = GEO[model]
+    W, H, _parts, C, maxp = GEO[model]
     thr = orc.default_thresholds(model)
     base = _synth.smooth_field(C, H // 8, W // 8, seed=5, scale=1.0)[None]
-    res_r, pk_r, nr, jr = _chain(model, base, thr)
+    res_r, _pk_r, nr, jr = _chain(model, base, thr)
     # (a) knock ONE clear maximum out of the engine-side maps (a bug that loses a peak): the deviation elsewhere stays tiny
     broken = base.copy()
     p = 3
@@ -224,7 +224,7 @@ class _FakeEngine:
 @pytest.mark.parametrize("model", [0, 1])
 def test_bench_parity_report_with_structured_leg_on_a_stand_in_engine(model):
     b = _bench()
-    W, H, parts, C, maxp = GEO[model]
+    W, H, _parts, C, _maxp = GEO[model]
     ref = (_synth.smooth_field(C, H // 8, W // 8, seed=9, scale=1.0)[None] * np.float32(4.0)).astype(np.float32)   # a map maximum of 4, like the synthetic network's
     dev = (np.random.RandomState(3).uniform(-1, 1, ref.shape) * 6.5e-4).astype(np.float32)
     eng = _FakeEngine(model, ref, dev)
