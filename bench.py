@@ -372,6 +372,7 @@ def init_comm(prefer, rank, world, local):
         prefer = "nccl" if torch.cuda.is_available() else "gloo"
     if prefer == "nccl":
         try:
+            torch.cuda.set_device(local)            # every "cuda" tensor of the reductions below (dispatch.py) must live on THIS rank's device
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=120))
             t = torch.ones(1, device=torch.device("cuda", local))
             dist.all_reduce(t)                      # the first collective is where a broken RCCL shows
@@ -479,6 +480,15 @@ def main():
         return
 
     import caffe_rtpose_amd as r
+    pinned_to = None
+    if world > 1:   # like rtpose.bin's workers: this rank's threads next to its GPU, so the pinned staging buffers it fills are on that NUMA node
+        try:
+            cpus = r.device_local_cpus(local)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                pinned_to = f"{len(cpus)} CPUs local to GPU {local}"
+        except Exception:  # noqa: BLE001
+            pass
     seed = 1
     PREC = {"fp16": r.PREC_FP16, "fp32": r.PREC_FP32, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}
 
@@ -620,6 +630,7 @@ def main():
             if args.calibrate:
                 out["config"]["calibration"] = eng.calibration_report()
         if world > 1:
+            out["rank0_cpu_affinity"] = pinned_to
             out["comm_backend"] = comm
             if comm_note:
                 out["comm_note"] = comm_note

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -25,6 +26,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtpose_mi355x.h"
@@ -930,6 +932,34 @@ int upload_conv_weights(rtp_engine* e, int i) {
   return RTP_OK;
 }
 
+// Every layer of the plan: packed on a few host threads (52 M weights through the kernels' staging order, swizzle and fp8 conversions: the
+// longest part of creating or re-planning an engine when it runs on one thread), then uploaded into ONE host image of the arena with a
+// single copy.
+int upload_all_weights(rtp_engine* e) {
+  std::vector<unsigned char> image(e->weights_bytes, 0);
+  const int n = (int)e->convs.size();
+  const int nthr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, n}));
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    std::vector<unsigned char> pw;
+    std::vector<float> pb;
+    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      const ConvOp& c = e->convs[i];
+      if (e->prec == 0) pack_conv<_Float16>(e, c, e->w_ref[i], e->b_ref[i], &pw, &pb);
+      else pack_conv<float>(e, c, e->w_ref[i], e->b_ref[i], &pw, &pb);
+      memcpy(image.data() + c.w_off, pw.data(), pw.size());                      // disjoint ranges of the image
+      memcpy(image.data() + c.b_off, pb.data(), pb.size() * sizeof(float));
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nthr; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  SYNC_GUARD;
+  HIPCHK(e, hipMemcpy(e->dweights, image.data(), e->weights_bytes, hipMemcpyHostToDevice));
+  return RTP_OK;
+}
+
 // ---- launches -------------------------------------------------------------------------------
 void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProblem* pr) {
   memset(pr, 0, sizeof(*pr));
@@ -1574,8 +1604,7 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
     }
   }
   compute_wq_exp(e);
-  for (size_t i = 0; i < e->convs.size(); ++i)
-    if ((rc = upload_conv_weights(e, (int)i))) return rc;
+  if ((rc = upload_all_weights(e))) return rc;
   SYNC_GUARD;   // contexts (hipMemset of the arenas), the dry run's synchronisation, the graph captures
   e->ctx.resize(nctx);
   for (auto& c : e->ctx)

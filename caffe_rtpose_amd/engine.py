@@ -233,6 +233,18 @@ class Video:
             self.h = C.c_void_p()
 
 
+def device_local_cpus(device_id):
+    """rtp_device_local_cpus: the CPUs next to a GPU's PCI function as a list of ints ([] where the platform does not say)."""
+    buf = C.create_string_buffer(1024)
+    if lib.rtp_device_local_cpus(int(device_id), buf, len(buf)) <= 0:
+        return []
+    cpus = []
+    for part in buf.value.decode().split(","):
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
 def plan_summary(cfg):
     buf = C.create_string_buffer(1 << 20)
     n = lib.rtp_plan_summary(C.byref(cfg.c), buf, len(buf))
