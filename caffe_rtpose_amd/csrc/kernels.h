@@ -212,6 +212,8 @@ struct NmsParams {
   int src_planes, H, W, num_parts, max_peaks, nstrips, strip_rows;
   float threshold;
   unsigned long long* probe;  // diagnostics (RTP_NMS_PROBE): wall-clock stamps of the phases of one strip workgroup, [0] = count
+  int* clear_flag;            // production chain: the connect kernels' people counter / error flag, reset here (the write kernel runs right in
+                              // front of them on the same stream) instead of by a 4-byte fill launch of its own between the two
 };
 hipError_t launch_nms(const NmsParams& p, hipStream_t stream);
 // Production path: the same peaks WITHOUT materialising the resized map — each strip workgroup
@@ -220,6 +222,7 @@ hipError_t launch_nms(const NmsParams& p, hipStream_t stream);
 hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream);
 
 struct ConnectParams {
+  int counter_cleared;  // 1: *num_people was reset by the NMS write kernel in front of this chain (NmsParams::clear_flag)
   const float* heat;   // resized map [C][net_h][net_w]
   const float* peaks;  // [num_parts][max_peaks+1][3]
   float* joints;       // [max_people][num_parts][3]

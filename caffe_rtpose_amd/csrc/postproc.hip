@@ -647,6 +647,7 @@ __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, Resiz
   const int part = blockIdx.x;
   const int tid = threadIdx.x;
   __shared__ ScaleGeo geo[RTP_MAX_SCALES];
+  if (p.clear_flag && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *p.clear_flag = 0;
   if (tid == 0) {
     int run = 0;
     for (int i = 0; i < p.nstrips; ++i) {
@@ -1261,7 +1262,7 @@ __global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) 
 }
 
 static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams* r, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
+  hipError_t e = p.counter_cleared ? hipSuccess : hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   const int cap = p.max_peaks * p.max_peaks;
   size_t n2 = 64;

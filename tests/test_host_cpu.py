@@ -453,6 +453,13 @@ def test_split_precision_plan_and_rule_syntax():
     assert " passes 2q " in dflt["conv3_2"] and " passes 2q " in dflt["Mconv3_stage6_L1"] and " passes 1 " in dflt["Mconv3_stage3_L1"]
     assert " passes 1 " in lines["conv3_1"]
     assert " passes 3aw/3aw " in lines["Mconv6_stage6_L1"]   # the fused 1x1 pair: passes of the first / second layer
+    # ":x" (what the load-time calibration switches a group to): both operands split, the corrections as fp16 passes instead of the fp8 chunk;
+    # a later rule for the same layers wins over the plain rule in front of it, other groups keep their fp8 chunk
+    x = {ln.split()[2]: ln for ln in r.plan_summary(r.Config(precision=r.PREC_MIXED, batch_frames=2, split_layers="conv2_,conv3_,*_stage5_,*_stage5_:x,@1x1")).splitlines()
+         if ln.startswith(("step conv", "step pw2"))}
+    assert " passes 3aw " in x["Mconv2_stage5_L1"] and " passes 3aw " in x["Mconv1_stage5_L1"] and " passes 2q " in x["conv3_2"] and " passes 1 " in x["Mconv2_stage4_L1"]
+    cost = lambda sp: float([ln for ln in r.plan_summary(r.Config(precision=r.PREC_MIXED, split_layers=sp)).splitlines() if ln.startswith("mfma_gflop")][0].split()[1])
+    assert cost("*_stage5_:x") > cost("*_stage5_") > cost("@1x1")       # three pass-times > two > one on those layers
 
 
 def test_eighth_resolution_launches_leave_cus_free():

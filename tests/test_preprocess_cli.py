@@ -57,6 +57,21 @@ def test_warp_display_scale_and_border():
     assert r.lib.rtp_display_fit_scale(640, 480, 1280, 720) == 1.5  # BASELINE config 1
 
 
+def test_display_fit_warp_is_a_copy_when_the_frame_has_the_display_size():
+    """rtpose.cpp:324-336 warps every frame to the display resolution with INTER_CUBIC.  At fit scale 1 the warp samples at integer
+    positions, where the cubic weights are (0, 1, 0, 0): a copy.  The engine skips the warp kernel for such frames (a 720p video at the
+    default --resolution 1280x720: 20 us per frame) and reads the frame itself as the display image; this is the host restatement of
+    OpenCV's arithmetic (tests/_cvref.py pins it) saying that nothing changes, for any content."""
+    import caffe_rtpose_amd as r
+    rs = np.random.RandomState(11)
+    for w, h in ((1280, 720), (640, 480), (333, 517), (16, 16)):
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        out, scale = r.warp_display(img, w, h)
+        assert scale == 1.0 and np.array_equal(out, img), (w, h)
+    out, scale = r.warp_display(np.full((480, 640, 3), 255, np.uint8), 1280, 720)   # (a frame that does NOT fit is resampled: scale 1.5, zero border)
+    assert scale == 1.5 and out.shape == (720, 1280, 3) and (out[:, 960:] == 0).all()
+
+
 def test_preprocess_frame_layout():
     import caffe_rtpose_amd as r
     img = r.synth_frame(640, 480, 3, seed=1)
