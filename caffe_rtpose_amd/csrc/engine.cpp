@@ -121,6 +121,7 @@ struct Slot {
   int* conn = nullptr;
   float* conn_score = nullptr;
   int* conn_count = nullptr;
+  int* tickets = nullptr;       // connect_chain_kernel's tickets (num_limbs + 1 zeros)
   float* joints = nullptr;
   int* num_people = nullptr;
   float* host_out = nullptr;  // pinned: [1 int as float slot][joints]
@@ -226,6 +227,11 @@ struct rtp_engine {
   // priority.  Measured (profiles/r04_input_staging.txt, host u8 frames, 7 in flight): 0: 1045 frames/s, 1: 880-890, 2: 880-990 — the
   // runtime multiplexes streams onto 4 hardware queues, and a staging stream's barrier (kernel behind a PCIe copy) then blocks whichever
   // conv / post-processing stream shares its queue.  Experiments build only (RTP_IN_STREAM).
+  // 1 = the connect chain (pairs -> match -> assemble) as ONE launch (connect_chain_kernel: tickets; experiments build, RTP_CHAIN_CONNECT=1).
+  // Bit-identical (GPU test) and no faster: 67.5 vs 67.7 us for one planted person, 97.5 vs 96.5 us on noise maps, 1033 vs 1039 frames/s —
+  // on a chip of 8 XCDs the device-scope release / acquire between the phases is an L2 write-back / invalidate, i.e. what a kernel boundary
+  // costs (with a fence per THREAD instead of per workgroup the first version took 24 us more).  profiles/r04_experiments.txt.
+  int chain_connect = 0;
   int in_stream_mode = 0;
   // 1 = deferred pre-processing (experiments build, RTP_PREP_DEFER): a frame's copy goes to a copy-only stream, its kernels are enqueued on
   // the conv stream once the copy has COMPLETED (polled at the next API call), a full batch whose last frame was just copied is launched at
@@ -1217,6 +1223,7 @@ int run_post_fused(rtp_engine* e, Ctx& cx, int sj, hipEvent_t ev_nms) {
   HIPCHK(e, hipEventRecord(ev_nms, sl.stream));
   ConnectParams cp = connect_params(e, cx, sj);
   cp.counter_cleared = 1;
+  cp.tickets = e->chain_connect ? sl.tickets : nullptr;
   HIPCHK(e, launch_connect_fused(cp, rp, sl.stream));
   return RTP_OK;
 }
@@ -1392,6 +1399,8 @@ int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   HIPCHK(e, hipMalloc((void**)&sl.conn, (size_t)e->num_limbs * e->max_peaks * 2 * sizeof(int)));
   HIPCHK(e, hipMalloc((void**)&sl.conn_score, (size_t)e->num_limbs * e->max_peaks * sizeof(float)));
   HIPCHK(e, hipMalloc((void**)&sl.conn_count, e->num_limbs * sizeof(int)));
+  HIPCHK(e, hipMalloc((void**)&sl.tickets, (e->num_limbs + 1) * sizeof(int)));
+  HIPCHK(e, hipMemset(sl.tickets, 0, (e->num_limbs + 1) * sizeof(int)));
   const size_t jfloats = (size_t)RTP_MAX_PEOPLE * e->num_parts * 3;
   HIPCHK(e, hipMalloc((void**)&sl.joints, jfloats * sizeof(float)));
   HIPCHK(e, hipMemset(sl.joints, 0, jfloats * sizeof(float)));
@@ -1453,7 +1462,7 @@ void free_ctx(Ctx& cx) {
   for (Slot& sl : cx.slot) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     void* dptrs[] = {sl.resized, sl.peaks, sl.strip_count, sl.strip_list, sl.cand_score, sl.cand_ij, sl.cand_count, sl.cand_blk, sl.conn, sl.conn_score,
-                     sl.conn_count, sl.joints, sl.num_people, sl.frame_dev, sl.disp_dev, sl.render_dev, sl.render_tab};
+                     sl.conn_count, sl.tickets, sl.joints, sl.num_people, sl.frame_dev, sl.disp_dev, sl.render_dev, sl.render_tab};
     for (void* p : dptrs) if (p) (void)hipFree(p);
     if (sl.frame_host) (void)hipHostFree(sl.frame_host);
     if (sl.render_host) (void)hipHostFree(sl.render_host);
@@ -1844,6 +1853,8 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
     e->graph_post = gp && gp[0] == '1';
     const char* im = RTP_EXP_ENV("RTP_IN_STREAM");   // experiments: 0 = stage inputs on the conv stream, 1 = own stream, 2 = own high-priority stream
     if (im) e->in_stream_mode = atoi(im);
+    const char* cc = RTP_EXP_ENV("RTP_CHAIN_CONNECT");
+    if (cc) e->chain_connect = atoi(cc);
     const char* pd = RTP_EXP_ENV("RTP_PREP_DEFER");   // experiments: 0 / 1 = pre-processing kernels right behind the copy / once the copy has completed
     if (pd) e->prep_defer = atoi(pd);
     if (e->B == 1) e->prep_defer = 0;   // a batch of one frame is launched by the submit that stages it: nothing to defer, the copy stays on the conv stream

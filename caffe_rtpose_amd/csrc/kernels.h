@@ -223,6 +223,8 @@ hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream
 
 struct ConnectParams {
   int counter_cleared;  // 1: *num_people was reset by the NMS write kernel in front of this chain (NmsParams::clear_flag)
+  int* tickets;         // [num_limbs + 1] zeros (device): non-null = the production chain runs as ONE launch (connect_chain_kernel): per-limb tickets of
+                        // the pair workgroups + one of the limbs; the kernel leaves them zero again
   const float* heat;   // resized map [C][net_h][net_w]
   const float* peaks;  // [num_parts][max_peaks+1][3]
   float* joints;       // [max_people][num_parts][3]

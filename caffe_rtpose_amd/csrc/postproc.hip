@@ -21,6 +21,7 @@
 //            raster order, ballot-compacted; then lane 0 runs the libstdc++-exact sort and the
 //            greedy assignment) and a single-wavefront assembly kernel that keeps the person
 //            table in LDS and parallelises the row searches over the 64 lanes.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -794,8 +795,7 @@ __device__ __forceinline__ void limb_setup(const ConnectParams& p, int k, const 
 // frame) become 76 dense ones.  Survivors are still compacted per block of 256 pairs (cand_blk), so the results are unchanged.
 #define PAIRS_WG 1024
 template <bool FUSED>
-__global__ __launch_bounds__(PAIRS_WG) void connect_pairs_kernel(ConnectParams p, ResizeParams r, int stage) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__device__ __forceinline__ void connect_pairs_body(const ConnectParams& p, const ResizeParams& r, const int stage, unsigned char* lds_raw) {
   const int k = blockIdx.y;
   const int cap = p.max_peaks * p.max_peaks;
   const bool coco = p.model == 0;
@@ -902,6 +902,11 @@ __global__ __launch_bounds__(PAIRS_WG) void connect_pairs_kernel(ConnectParams p
   }
   if ((threadIdx.x & 255) == 0 && blk256 < nblk256)
     p.cand_blk[k * nblk256 + blk256] = wave_cnt[sub * 4] + wave_cnt[sub * 4 + 1] + wave_cnt[sub * 4 + 2] + wave_cnt[sub * 4 + 3];
+}
+template <bool FUSED>
+__global__ __launch_bounds__(PAIRS_WG) void connect_pairs_kernel(ConnectParams p, ResizeParams r, int stage) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  connect_pairs_body<FUSED>(p, r, stage, lds_raw);
 }
 
 // 64-bit sort key: ascending key order == (score descending, loop order ascending)
@@ -1114,8 +1119,7 @@ __global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
 // written, so the scan can be turned inside out: ONE pass over the rows looks up the connection
 // owning the row's partA peak (conn_of[]), updates the row, and marks the connection as matched;
 // unmatched connections then append their rows in connection order, exactly as the serial loop.
-__global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__device__ __forceinline__ void connect_assemble_body(const ConnectParams& p, unsigned char* lds_raw) {
   const int NP = p.num_parts;
   double* sscore = (double*)lds_raw;                       // [max_rows]
   short* scnt = (short*)(sscore + p.max_rows);             // [max_rows]
@@ -1260,6 +1264,39 @@ __global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) 
   }
   if (tid == 0) *p.num_people = out < p.max_people ? out : p.max_people;
 }
+__global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  connect_assemble_body(p, lds_raw);
+}
+
+#ifdef RTP_EXPERIMENTS
+// The whole connect chain in ONE launch (experiments build, RTP_CHAIN_CONNECT=1; round 4): the grid of the pair kernel.  The LAST workgroup of a limb to
+// finish its pairs (a ticket per limb) orders that limb's candidates and runs its greedy assignment with its first four waves (the other
+// twelve retire: s_barrier only waits for the surviving waves of a workgroup), and the last LIMB to finish assembles the people.  Two
+// launches and their dependency latencies less per frame; the arithmetic is the three kernels', called as they are.
+// Visibility: every producer ends with __threadfence() before its ticket (release), every consumer starts with one after it (acquire:
+// nothing of the produced data was read by this workgroup before, and the vector L1 is invalidated by the fence).
+__global__ __launch_bounds__(PAIRS_WG) void connect_chain_kernel(ConnectParams p, ResizeParams r, int stage) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int s_last;
+  connect_pairs_body<true>(p, r, stage, lds_raw);
+  // release: every thread's stores have left the CU (vmcnt 0), the barrier collects them, ONE thread issues the device-scope fence (on a
+  // multi-XCD chip that is an L2 write-back: 1024 threads x 76 workgroups doing it each was the first version's 24 us) and takes the ticket
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(&p.tickets[blockIdx.y], 1) == (int)gridDim.x - 1; if (s_last) __threadfence(); }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 256) return;   // (uniform per wave)
+  connect_match_limb(p, blockIdx.y, lds_raw);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(&p.tickets[p.num_limbs], 1) == p.num_limbs - 1; if (s_last) __threadfence(); }
+  __syncthreads();
+  if (!s_last) return;
+  if ((int)threadIdx.x <= p.num_limbs) p.tickets[threadIdx.x] = 0;   // ready for the next frame (nobody else is alive in this launch)
+  connect_assemble_body(p, lds_raw);
+}
+#endif
 
 static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams* r, hipStream_t stream) {
   hipError_t e = p.counter_cleared ? hipSuccess : hipMemsetAsync(p.num_people, 0, sizeof(int), stream);
@@ -1285,6 +1322,19 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
     e = ensure_lds<connect_assemble_kernel>(lds2);
     if (e != hipSuccess) return e;
   }
+#ifdef RTP_EXPERIMENTS
+  if (r && p.tickets && p.counter_cleared && !p.diag_stages) {   // pairs -> match -> assemble in one launch
+    const size_t lds0 = (size_t)2 * r->num * r->h * r->w * sizeof(float);
+    const int stage = lds0 <= 96 * 1024 ? 1 : 0;
+    const size_t lds = std::max(std::max(stage ? lds0 : (size_t)0, lds1), lds2);
+    if (lds > 64 * 1024) {
+      e = ensure_lds<connect_chain_kernel>(lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(connect_chain_kernel, dim3((cap + PAIRS_WG - 1) / PAIRS_WG, p.num_limbs), dim3(PAIRS_WG), lds, stream, pa, *r, stage);
+    return hipGetLastError();
+  }
+#endif
   if (r) {
     const size_t lds0 = (size_t)2 * r->num * r->h * r->w * sizeof(float);
     const int stage = lds0 <= 96 * 1024 ? 1 : 0;

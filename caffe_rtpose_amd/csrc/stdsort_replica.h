@@ -133,7 +133,13 @@ RTP_HD inline void std_sort_replica(Cand* v, int n) {
   // an explicit stack (depth <= 2*lg n <= 64).
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) ++lg;
+  // ONE thread of a workgroup runs this on the device (the connect kernel's rare exact path): the explicit stack lives in LDS there.  As
+  // private arrays it gave every wave of every launch of the kernel a 784-byte scratch segment (61 MB for the single-launch chain).
+#ifdef __HIP_DEVICE_COMPILE__
+  __shared__ int stack_first[64], stack_last[64], stack_depth[64];
+#else
   int stack_first[64], stack_last[64], stack_depth[64];
+#endif
   int sp = 0;
   stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = 2 * lg;
   sp = 1;

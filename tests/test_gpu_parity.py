@@ -798,5 +798,6 @@ def test_deferred_preprocessing_and_staging_streams_do_not_change_results():
         base = run(args)
         assert run(args, RTP_LIB=exp, RTP_PREP_DEFER="1") == base, args
         assert run(args, RTP_LIB=exp, RTP_PREP_DEFER="0") == base, args
+    assert run(["2", "7"], RTP_LIB=exp, RTP_CHAIN_CONNECT="1") == run(["2", "7"])     # pairs -> match -> assemble as one launch (tickets)
     assert run(["2", "7"], RTP_LIB=exp, RTP_IN_STREAM="1") == run(["2", "7"])
     assert run(["2", "7"], RTP_LIB=exp, RTP_IN_STREAM="2", RTP_PREP_DEFER="1") == run(["2", "7"])
