@@ -164,7 +164,7 @@ def cpu_baseline(eng, num_scales, model="coco", frames=3, oracle=None):
     return out
 
 
-def parity_report(eng, fr, model, num_scales, scale_gap, structured=True):
+def parity_report(eng, fr, model, num_scales, scale_gap, structured=True, start_scale=1.0):
     """SURVEY section 7 / BASELINE.md section 3: the engine's joints (this precision mode, through rtp_submit / rtp_collect) against the
     full fp32 oracle chain conv -> ImResize -> Nms -> connectLimbs* on the same frames, as SETS of people (tests/_parity.py).
     Units: the synthetic network's maps have a maximum of ~5 where real confidences live in [0, 1]; scores and map errors are
@@ -187,7 +187,7 @@ def parity_report(eng, fr, model, num_scales, scale_gap, structured=True):
     reps, exps, map_err, post_exact, dev = [], [], 0.0, True, None
     for x, ref, _ in fr:
         norm = float(np.abs(ref).max())
-        res = orc.imresize(ref, W, H, 1.0, scale_gap)[0]
+        res = orc.imresize(ref, W, H, start_scale, scale_gap)[0]
         peaks = orc.nms(res, parts, max_peaks, th["nms_threshold"])
         nr, jr = orc.connect(mid, res, peaks, max_peaks, W, H, 1280, 720, th)
         eng.submit(x, tag=1)
@@ -200,7 +200,7 @@ def parity_report(eng, fr, model, num_scales, scale_gap, structured=True):
             dev = (got - ref) / norm       # the conv stack's measured deviation field, in units of the map maximum
         # decomposition: the reference's post-processing applied to the ENGINE's maps must give the engine's joints bit for bit;
         # whatever differs between the two people sets is then decided by strict compares on maps that differ by <= map_err
-        res_e = orc.imresize(got, W, H, 1.0, scale_gap)[0]
+        res_e = orc.imresize(got, W, H, start_scale, scale_gap)[0]
         n2, j2 = orc.connect(mid, res_e, orc.nms(res_e, parts, max_peaks, th["nms_threshold"]), max_peaks, W, H, 1280, 720, th)
         post_exact = post_exact and n2 == ne and np.array_equal(j2[:n2], je[:ne])
         ex1 = _explain.explain(mid, res, res_e, max_peaks, W, H, 1280, 720, th, rep["structural"], tol_px=1.0, tol_c=1e-3, c_norm=norm, out_of_tol=rep["out_of_tol"])
@@ -220,13 +220,13 @@ def parity_report(eng, fr, model, num_scales, scale_gap, structured=True):
     tot["verdict"] = _parity.verdict(tot, map_err=map_err, post_exact=post_exact, explained=ex["structural_explained"] if ex["unexplained"] == 0 else 0)
     if structured and dev is not None:
         try:
-            tot["structured"] = structured_parity(eng, model, dev, scale_gap)
+            tot["structured"] = structured_parity(eng, model, dev, scale_gap, start_scale)
         except Exception as ex2:  # noqa: BLE001
             tot["structured"] = {"verdict": f"FAIL: {ex2}"}
     return tot
 
 
-def structured_parity(eng, model, dev, scale_gap):
+def structured_parity(eng, model, dev, scale_gap, start_scale=1.0):
     """Conv -> JSON parity on maps that LOOK like pose maps.  No trained weights exist offline, so the maps are
     planted: P = 1 / 5 / 20 stick figures as analytic low-res heat maps + PAFs (tests/_synth.people_lowres, values in [0, 1]).  The
     reference side runs them through the fp32 oracle chain; the engine side gets the same maps PLUS the conv stack's MEASURED deviation
@@ -251,16 +251,20 @@ def structured_parity(eng, model, dev, scale_gap):
            "what": "planted people + the engine's measured conv deviation -> device post-processing, vs planted people -> fp32 oracle chain"}
     ok, flips_total = True, 0
     for P in (1, 5, 20):
-        low, _people = _synth.people_lowres(mid, tables, P, eng.low_h, eng.low_w, seed=3 + P, N=eng.N)
+        if start_scale == 1.0:
+            low, _people = _synth.people_lowres(mid, tables, P, eng.low_h, eng.low_w, seed=3 + P, N=eng.N)
+        else:   # --start_scale != 1: every scale's copy of the people lives in that scale's crop window (imresize_layer.cu:110-113)
+            import _pincases
+            low = _pincases.scaled_people(mid, tables, P, eng.low_h, eng.low_w, 3 + P, eng.N, start_scale, scale_gap)
         s = float(np.abs(low).max())
         low_e = np.ascontiguousarray(low + dev * np.float32(s), np.float32)
-        res = orc.imresize(low, W, H, 1.0, scale_gap)[0]
+        res = orc.imresize(low, W, H, start_scale, scale_gap)[0]
         nr, jr = orc.connect(mid, res, orc.nms(res, parts, max_peaks, th["nms_threshold"]), max_peaks, W, H, 1280, 720, th)
         _, je, ne = eng.post_from_lowres(low_e)
         rep = _parity.people_parity(je[:ne], jr[:nr], tol_px=1.0, tol_c=1e-3, c_norm=s)
         explained = None
         if rep["joints_structural"] or rep["numeric_out_of_tol"]:
-            ex = _explain.explain(mid, res, orc.imresize(low_e, W, H, 1.0, scale_gap)[0], max_peaks, W, H, 1280, 720, th, rep["structural"],
+            ex = _explain.explain(mid, res, orc.imresize(low_e, W, H, start_scale, scale_gap)[0], max_peaks, W, H, 1280, 720, th, rep["structural"],
                                   tol_px=1.0, tol_c=1e-3, c_norm=s, out_of_tol=rep["out_of_tol"])
             _parity.reclassify(rep, ex["out_of_tol_is_flip"])
             explained = ex["structural_explained"] if ex["unexplained"] == 0 else 0

@@ -1797,6 +1797,19 @@ void rtp_engine_destroy(rtp_engine* e) {
   delete e;
 }
 
+// CHECK_LE(target_width, NET_RESOLUTION_WIDTH) / CHECK_LE(target_height, ..) (rtpose.cpp:363-364, 513-514): every scale
+// s = start_scale - i * scale_gap (the producer's own arithmetic: double, then float, :360) must be positive and its 16-aligned target
+// must fit the net input; NaN / inf never do.  The same test guards ImResize's crops (imresize_layer.cu:110-113: padw >= 0, ow >= 1).
+static bool scales_fit(int net_w, int net_h, int num_scales, float start_scale, float scale_gap, int* bad, float* bad_s) {
+  for (int i = 0; i < num_scales; ++i) {
+    const float s = (float)((double)start_scale - i * (double)scale_gap);
+    const bool ok = s > 0.f && 16 * std::ceil(net_w * s / 16) <= net_w && 16 * std::ceil(net_h * s / 16) <= net_h &&
+                    16 * std::ceil(net_w * s / 16) >= 16 && 16 * std::ceil(net_h * s / 16) >= 16;
+    if (!ok) { if (bad) *bad = i; if (bad_s) *bad_s = s; return false; }
+  }
+  return true;
+}
+
 static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (!cfg || !out) return fail(nullptr, RTP_EINVAL, "null argument");
   *out = nullptr;
@@ -1812,11 +1825,13 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (cfg->precision < RTP_PREC_FP16 || cfg->precision > RTP_PREC_F16X3) return fail(nullptr, RTP_EINVAL, "unknown precision %d", cfg->precision);
   if (cfg->exec_mode != RTP_EXEC_GRAPH && cfg->exec_mode != RTP_EXEC_EAGER) return fail(nullptr, RTP_EINVAL, "unknown exec_mode %d", cfg->exec_mode);
   if (cfg->disp_w < 1 || cfg->disp_h < 1) return fail(nullptr, RTP_EINVAL, "bad display resolution");
-  // CHECK_LE(target_width, NET_RESOLUTION_WIDTH) (rtpose.cpp:363): every scale must fit the net input
-  for (int i = 0; i < cfg->num_scales; ++i) {
-    const float s = cfg->start_scale - i * cfg->scale_gap;
-    if (!(s > 0.f) || 16 * std::ceil(cfg->net_w * s / 16) > cfg->net_w || 16 * std::ceil(cfg->net_h * s / 16) > cfg->net_h)
-      return fail(nullptr, RTP_EINVAL, "scale %d (%.3f) does not fit the net resolution", i, s);
+  if ((cfg->net_w % 16) || (cfg->net_h % 16) || cfg->net_w < 16 || cfg->net_h < 16)
+    return fail(nullptr, RTP_EINVAL, "net_resolution %dx%d must be positive multiples of 16", cfg->net_w, cfg->net_h);
+  {
+    int bad = -1;
+    float s = 0.f;
+    if (!scales_fit(cfg->net_w, cfg->net_h, cfg->num_scales, cfg->start_scale, cfg->scale_gap, &bad, &s))
+      return fail(nullptr, RTP_EINVAL, "scale %d (%.3f) does not fit the net resolution", bad, s);
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, RTP_ENODEV, "no HIP device visible: this engine has no CPU fallback");
@@ -1952,8 +1967,16 @@ int rtp_get_thresholds(const rtp_engine* e, float* a, float* b, int* c, int* d, 
 int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap) {
   SYNC_GUARD;
   if (!e) return RTP_EINVAL;
+  {
+    int bad = -1;
+    float s = 0.f;
+    if (!scales_fit(e->cfg.net_w, e->cfg.net_h, e->N, start_scale, scale_gap, &bad, &s))   // nothing is changed by a refused call
+      return fail(e, RTP_EINVAL, "rtp_set_scales: scale %d (%.3f) does not fit the net resolution (rtpose.cpp:363)", bad, s);
+  }
   e->start_scale = start_scale;
   e->scale_gap = scale_gap;
+  e->cfg.start_scale = start_scale;
+  e->cfg.scale_gap = scale_gap;
   if (!e->ctx.empty()) {
     int rc;
     if ((rc = use_device(e))) return rc;

@@ -850,13 +850,18 @@ __device__ __forceinline__ void connect_pairs_body(const ConnectParams& p, const
     bool bad = false;
 #pragma unroll
     for (int lm = 0; lm < num_inter; lm++) {
-      int my = (int)roundf(s_y + lm * d_y / num_inter);
-      int mx = (int)roundf(s_x + lm * d_x / num_inter);
+      const float ry = roundf(s_y + lm * d_y / num_inter), rx = roundf(s_x + lm * d_x / num_inter);
+      int my = (int)ry;
+      int mx = (int)rx;
       if (coco) {
         if (mx >= NW) mx = NW - 1;
         if (my >= NH) my = NH - 1;
       }
-      if (mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; mx = 0; my = 0; }
+      // A NaN or a value beyond int is "integer indefinite" = INT_MIN in the reference's host conversion (cvttss2si), i.e. its
+      // CHECK_GE(mx, 0) fails; v_cvt_i32_f32 would give 0 / INT_MAX instead.  Reached by a net that is taller than wide: the write
+      // kernel's centroid window is bounded by `width` in y too (nms_layer.cu:79) and divides 0 by 0 for peaks below row width + 3.
+      const bool indef = !(rx >= -2147483648.f && rx < 2147483648.f) || !(ry >= -2147483648.f && ry < 2147483648.f);
+      if (indef || mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; mx = 0; my = 0; }
       idxs[lm] = my * NW + mx;
     }
     float px[10], py[10];

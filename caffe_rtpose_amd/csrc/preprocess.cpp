@@ -242,7 +242,9 @@ int rtp_warp_display(const unsigned char* bgr, int sw, int sh, unsigned char* ou
 // net_w) and Frame::scale.  display_bgr (disp_h x disp_w x 3) may be NULL.
 int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h, int num_scales,
                          double start_scale, double scale_gap, float* net_input, unsigned char* display_bgr, float* frame_scale) {
-  if (!bgr || !net_input || w < 1 || h < 1 || num_scales < 1) return RTP_EINVAL;
+  if (!bgr || !net_input || w < 1 || h < 1 || num_scales < 1 || disp_w < 1 || disp_h < 1 || net_w < 16 || net_h < 16 || (net_w % 16) || (net_h % 16) ||
+      !(start_scale == start_scale) || !(scale_gap == scale_gap))
+    return RTP_EINVAL;
   std::vector<unsigned char> disp((size_t)disp_w * disp_h * 3);
   double s = 0;
   int rc = rtp_warp_display(bgr, w, h, disp.data(), disp_w, disp_h, &s);

@@ -180,7 +180,7 @@ struct Global {
   std::atomic<double> last_written{0};         // (by the display thread, or by whichever JSON writer finished last)
   BlockingQueue<Frame> json_queue;             // --json_writers K
   std::atomic<bool> json_done{false};
-  int num_parts = 18;
+  std::atomic<int> num_parts{18};              // every worker stores the same value (its engine's) while the JSON writers read it
   std::vector<std::string> image_list;
 };
 
@@ -357,19 +357,22 @@ void worker(int widx, int device, int* status) {
     if (widx == 0) G.engine0 = e;
     else {
       while (!G.engine0.load() && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-      if (G.engine0.load() && rtp_copy_weights_from(e, G.engine0.load()) != RTP_OK) {
-        fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(e));
-        *status = 1;
-        G.quit_threads = true;
-        rtp_engine_destroy(e);
-        return;
+      rtp_engine* src = G.engine0.load();
+      if (src) {   // (null: worker 0 failed and everybody is quitting — nothing was copied, nothing is counted)
+        if (rtp_copy_weights_from(e, src) != RTP_OK) {
+          fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(e));
+          *status = 1;
+          G.quit_threads = true;
+          rtp_engine_destroy(e);
+          return;
+        }
+        G.weights_shared++;
       }
-      G.weights_shared++;
     }
   }
   int num_parts = F.model == "mpi" ? 15 : 18;
   if (!dry) rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
-  G.num_parts = num_parts;
+  G.num_parts.store(num_parts);
   // --dry_engine: what the engine costs the HOST per frame (the staging copy of rtp_submit_frame, the joints copy of
   // rtp_collect) and when a frame completes (RATE frames/s, at least two frame times after its submit)
   std::vector<unsigned char> dry_staging;
@@ -384,7 +387,7 @@ void worker(int widx, int device, int* status) {
     dry_done.push_back(dry_last);
     return RTP_OK;
   };
-  auto dry_collect = [&](const Frame& fr, float* joints, int* n) {
+  auto dry_collect = [&](Frame& fr, float* joints, int* n) {
     const double t = dry_done.front();
     dry_done.pop_front();
     for (double now = wall(); now < t; now = wall()) std::this_thread::sleep_for(std::chrono::duration<double>(std::min(t - now, 0.0005)));
@@ -397,6 +400,7 @@ void worker(int widx, int device, int* status) {
       joints[3 * i + 2] = (float)((r >> 40) % 1000) / 1000.f;
     }
     *n = P;
+    if (!fr.rendered.empty()) memset(fr.rendered.data(), 40 + (fr.index * 7) % 160, fr.rendered.size());  // --write_frames: what the encoders get instead of rtp_collect_rendered's frame
     return RTP_OK;
   };
   fprintf(stderr, dry ? "dry worker %d is ready (%.0f frames/s)\n" : "GPU %d is ready\n", device, F.dry_engine);
@@ -516,7 +520,7 @@ void write_json_file(const Frame& fr, std::vector<char>& buf) {
   char fname[1024];
   if (F.image_dir.empty()) snprintf(fname, sizeof fname, "%s/frame%06d.json", F.write_json.c_str(), fr.video_frame_number);  // :1388
   else snprintf(fname, sizeof fname, "%s/%s.json", F.write_json.c_str(), fr.stem.c_str());                                   // :1390-1393
-  const long n = rtp_format_json(buf.data(), buf.size(), fr.joints.data(), fr.numPeople, G.num_parts, fr.scale);
+  const long n = rtp_format_json(buf.data(), buf.size(), fr.joints.data(), fr.numPeople, G.num_parts.load(), fr.scale);
   if (n >= 0) {
     FILE* f = fopen(fname, "wb");
     if (f) { fwrite(buf.data(), 1, (size_t)n, f); fclose(f); }
@@ -638,7 +642,6 @@ int main(int argc, char** argv) {
   if (F.batch_frames < 1 || F.batch_frames > 16) { fprintf(stderr, "--batch_frames must be in [1, 16]\n"); return 1; }
   if (F.json_writers < 0) F.json_writers = F.num_gpu;
   if (F.dry_engine < 0 || F.json_writers > 64) { fprintf(stderr, "--dry_engine must be >= 0 and --json_writers in [0, 64]\n"); return 1; }
-  if (F.dry_engine > 0 && !F.write_frames.empty()) { fprintf(stderr, "--dry_engine has no renderer: drop --write_frames\n"); return 1; }
   std::vector<int> devs;
   for (int g = 0; g < F.num_gpu; ++g) devs.push_back(g + F.start_device);  // rtpose.cpp:1466
   if (!F.devices.empty()) {

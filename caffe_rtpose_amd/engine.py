@@ -11,6 +11,10 @@ EXEC_GRAPH, EXEC_EAGER = 0, 1
 MAX_PEOPLE = 96
 
 
+# error codes of include/rtpose_mi355x.h
+RTP_OK, RTP_EINVAL, RTP_ENOMEM, RTP_ENODEV, RTP_EIO, RTP_EAGAIN, RTP_EHIP, RTP_ERANGE = 0, -22, -12, -19, -5, -11, -70, -34
+
+
 class RtpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"rtp error {code}: {msg}")

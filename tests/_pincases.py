@@ -19,6 +19,36 @@ def digest(a):
     return hashlib.sha256(a.tobytes()).hexdigest()
 
 
+def crop_of(h, w, start, gap, n):
+    """(padh, padw, oh, ow) of scale n inside the h x w low-res map: imresize_layer.cu:110-113 in its own float arithmetic
+    (integer w/2, float32 products, floor)."""
+    f = np.float32
+    t = f(f(1) - f(start)) + f(f(n) * f(gap))
+    padw = int(np.floor(f(w // 2) * t))
+    padh = int(np.floor(f(h // 2) * t))
+    return padh, padw, h - 2 * padh, w - 2 * padw
+
+
+def scaled_people(model, tables, P, h, w, seed, N, start, gap):
+    """Planted people whose scale n copy lives where the producer puts it (rtpose.cpp:353-368: the image resized by start - n gap,
+    centre-padded): the same people, planted at the crop's size in the crop's window, zeros (+ tie-breaking noise) around it."""
+    out = np.zeros((N, DIMS[model][2], h, w), np.float32)
+    rs = np.random.RandomState(seed + 1000)
+    out += (rs.rand(*out.shape).astype(np.float32) - 0.5) * 1e-3
+    for n in range(N):
+        padh, padw, oh, ow = crop_of(h, w, start, gap, n)
+        out[n, :, padh:padh + oh, padw:padw + ow] = _synth.people_lowres(model, tables, P, oh, ow, seed=seed)[0][0]
+    return out
+
+
+# cases whose joints are scaled to another display resolution than 1280x720 (rtpose.cpp:1051-1073: peaks * DISP / NET)
+CASE_DISP = {"coco_s080_n2_disp640x360": (640, 360), "coco_noise_s080_n1_disp1920x1080": (1920, 1080), "portrait_people3_s080_n2": (720, 1280)}
+
+
+def disp_of(name):
+    return CASE_DISP.get(name, (1280, 720))
+
+
 def lowres_cases(tables):
     """name -> (model, lowres [N][C][h][w], net_w, net_h, start_scale, scale_gap)"""
     c = {}
@@ -30,7 +60,29 @@ def lowres_cases(tables):
         c[f"coco_people{P}"] = (0, _synth.people_lowres(0, tables[0], P, 46, 82, seed=20 + P)[0], 656, 368, 1.0, 0.3)
     c["coco_people5_3s"] = (0, _synth.people_lowres(0, tables[0], 5, 46, 82, seed=44, N=3)[0], 656, 368, 1.0, 0.15)
     c["mpi_people5"] = (1, _synth.people_lowres(1, tables[1], 5, 46, 62, seed=25)[0], 496, 368, 1.0, 0.3)
+    # round 5: --start_scale != 1 (rtpose.cpp:68; ImResizeLayer::SetStartScale moves the crop of EVERY scale incl. n = 0,
+    # imresize_layer.cu:110-113), portrait and large net resolutions, other display resolutions in connect (rtpose.cpp:1051-1073)
+    noise = lambda N, C, h, w, seed: _synth.smooth_field(N * C, h, w, seed=seed).reshape(N, C, h, w)
+    c["coco_noise_s080_n1"] = (0, noise(1, 57, 46, 82, 51), 656, 368, 0.8, 0.15)
+    c["coco_noise_s080_n2"] = (0, noise(2, 57, 46, 82, 52), 656, 368, 0.8, 0.15)
+    c["coco_noise_s080_n3"] = (0, noise(3, 57, 46, 82, 53), 656, 368, 0.8, 0.15)
+    c["coco_noise_s065_n1"] = (0, noise(1, 57, 46, 82, 54), 656, 368, 0.65, 0.25)
+    c["coco_noise_s065_n2"] = (0, noise(2, 57, 46, 82, 55), 656, 368, 0.65, 0.25)
+    c["coco_noise_s065_n3"] = (0, noise(3, 57, 46, 82, 56), 656, 368, 0.65, 0.25)     # scale 2 = 0.15: a 14 x 8 crop
+    c["coco_people5_s080_n3"] = (0, scaled_people(0, tables[0], 5, 46, 82, 57, 3, 0.8, 0.15), 656, 368, 0.8, 0.15)
+    c["mpi_people5_s080_n2"] = (1, scaled_people(1, tables[1], 5, 46, 62, 58, 2, 0.8, 0.25), 496, 368, 0.8, 0.25)
+    c["mpi_noise_s065_n2"] = (1, noise(2, 44, 46, 62, 59), 496, 368, 0.65, 0.15)
+    c["portrait_noise_1s"] = (0, noise(1, 57, 82, 46, 60), 368, 656, 1.0, 0.3)
+    c["portrait_people3_s080_n2"] = (0, scaled_people(0, tables[0], 3, 82, 46, 61, 2, 0.8, 0.15), 368, 656, 0.8, 0.15)
+    c["large_noise_s080_n2"] = (0, noise(2, 57, 92, 164, 62), 1312, 736, 0.8, 0.15)
+    c["coco_s080_n2_disp640x360"] = (0, scaled_people(0, tables[0], 5, 46, 82, 63, 2, 0.8, 0.15), 656, 368, 0.8, 0.15)
+    c["coco_noise_s080_n1_disp1920x1080"] = (0, noise(1, 57, 46, 82, 64), 656, 368, 0.8, 0.15)
     return c
+
+
+ROUND5_CASES = ["coco_noise_s080_n1", "coco_noise_s080_n2", "coco_noise_s080_n3", "coco_noise_s065_n1", "coco_noise_s065_n2", "coco_noise_s065_n3",
+                "coco_people5_s080_n3", "mpi_people5_s080_n2", "mpi_noise_s065_n2", "portrait_noise_1s", "portrait_people3_s080_n2",
+                "large_noise_s080_n2", "coco_s080_n2_disp640x360", "coco_noise_s080_n1_disp1920x1080"]
 
 
 def clamp_counts(peaks, max_peaks):
@@ -47,7 +99,13 @@ def chain(impl, model, low, net_w, net_h, start, gap, disp=(1280, 720)):
     thr = THR[model]
     res = impl.imresize(np.ascontiguousarray(low, np.float32), net_w, net_h, start, gap)[0]
     peaks = impl.nms(res, parts, max_peaks, thr["nms_threshold"])
-    n, joints = impl.connect(model, res, clamp_counts(peaks, max_peaks), max_peaks, net_w, net_h, disp[0], disp[1], thr)
+    try:
+        n, joints = impl.connect(model, res, clamp_counts(peaks, max_peaks), max_peaks, net_w, net_h, disp[0], disp[1], thr)
+    except (RuntimeError, AssertionError):
+        # the reference CHECK-fails (rtpose.cpp:928 CHECK_GE(mx, 0)); the oracle returns its error code; the engine RTP_ERANGE.  Reached by
+        # portrait nets: writeResultKernel bounds the centroid window's ROWS by `width` (nms_layer.cu:79), so a peak at y >= width + 3 of
+        # a net that is taller than wide divides 0 by 0, and connect rounds the NaN coordinate to INT_MIN.
+        return res, peaks, -1, np.zeros((0, parts, 3), np.float32)
     return res, peaks, n, joints[:n].copy()
 
 

@@ -131,13 +131,53 @@ def test_pooling_fused_into_the_convolution_epilogue_is_bit_identical(prec, mode
 # ImResize — bit exact
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("model,W,H,N,start,gap", [(0, 656, 368, 1, 1.0, 0.3), (0, 656, 368, 3, 1.0, 0.15),
-                                                    (1, 496, 368, 2, 1.0, 0.3), (0, 64, 48, 2, 1.0, 0.25)])
+                                                    (1, 496, 368, 2, 1.0, 0.3), (0, 64, 48, 2, 1.0, 0.25),
+                                                    # round 5: --start_scale != 1 moves the crop of EVERY scale (imresize_layer.cu:110-113),
+                                                    # portrait / large nets, crops down to 14 x 8 low-res cells
+                                                    (0, 656, 368, 1, 0.8, 0.15), (0, 656, 368, 2, 0.8, 0.15), (0, 656, 368, 3, 0.8, 0.15),
+                                                    (0, 656, 368, 1, 0.65, 0.25), (0, 656, 368, 3, 0.65, 0.25), (1, 496, 368, 2, 0.65, 0.15),
+                                                    (0, 368, 656, 2, 0.8, 0.15), (0, 1312, 736, 2, 0.8, 0.15), (0, 64, 48, 2, 0.7, 0.3)])
 def test_resize_bit_exact(model, W, H, N, start, gap):
     e = _engine(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, frames_in_flight=1)
     low = _synth.smooth_field(N * e.heat_channels, H // 8, W // 8, seed=3).reshape(N, e.heat_channels, H // 8, W // 8)
     got = e.resize(low)
     ref = orc.imresize(low, W, H, start, gap)[0]
     assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
+    e.close()
+
+
+def test_set_scales_and_submit_frame_refuse_out_of_contract_scales():
+    """ImResizeLayer::SetStartScale / SetScaleGap (imresize_layer.cpp) take anything and the producer CHECKs later (rtpose.cpp:363);
+    rtp_set_scales refuses what the producer would refuse — RTP_EINVAL, the engine keeps its old scales — and accepts start_scale < 1."""
+    import caffe_rtpose_amd as r
+    from test_host_cpu import BAD_GEOMETRY
+    for kw in BAD_GEOMETRY:
+        with pytest.raises(r.RtpError) as ei:
+            _engine(**{**dict(net_w=160, net_h=96, frames_in_flight=1), **kw})
+        assert ei.value.code == r.RTP_EINVAL, kw
+    e = _engine(net_w=160, net_h=96, num_scales=2, scale_gap=0.25, disp_w=320, disp_h=180, frames_in_flight=1)
+    low = _synth.smooth_field(2 * e.heat_channels, 12, 20, seed=5).reshape(2, e.heat_channels, 12, 20)
+    img = r.synth_frame(320, 180, 0, seed=2)
+    before = e.resize(low)
+    x0, _, _ = e.debug_preprocess(img)
+    nan = float("nan")
+    for s, g in ((1.2, 0.25), (0.2, 0.25), (nan, 0.25), (1.0, nan), (0.0, 0.1), (1.0, 1.0), (-1.0, -0.5), (float("inf"), 0.25)):
+        with pytest.raises(r.RtpError) as ei:
+            e.set_scales(s, g)
+        assert ei.value.code == r.RTP_EINVAL, (s, g)
+        assert np.array_equal(e.resize(low), before)          # a refused call changes nothing
+    assert np.array_equal(e.debug_preprocess(img)[0], x0)
+    e.submit_frame(img, tag=3)
+    assert e.collect()[0] == 3
+    e.set_scales(0.8, 0.3)                                    # in contract: levels 0.8 and 0.5
+    assert np.array_equal(e.resize(low), orc.imresize(low, 160, 96, 0.8, 0.3)[0])
+    want_x, _, _ = r.preprocess_frame(img, 320, 180, 160, 96, 2, 0.8, 0.3)
+    assert np.array_equal(e.debug_preprocess(img)[0], want_x)
+    e.submit_frame(img, tag=4)
+    t, n, j = e.collect()
+    e.submit(want_x, tag=5)
+    t2, n2, j2 = e.collect()
+    assert (t, t2) == (4, 5) and n == n2 and np.array_equal(j, j2)
     e.close()
 
 
@@ -379,6 +419,11 @@ def test_weights_roundtrip_caffemodel_and_prototxt(tmp_path):
     (640, 480, 1280, 720, 656, 368, 2, 1.0, 0.25),     # up-warp with a zero border on the right
     (333, 517, 640, 480, 320, 240, 4, 1.0, 0.2),       # odd sizes, portrait, 4 scales
     (640, 480, 656, 368, 656, 368, 1, 1.0, 0.3),       # display == net: identity level (memcpy branch)
+    (1280, 720, 1280, 720, 656, 368, 1, 0.8, 0.15),    # round 5: --start_scale != 1 (s = start_scale - i gap, rtpose.cpp:353-368)
+    (1280, 720, 1280, 720, 656, 368, 3, 0.8, 0.15),
+    (1920, 1080, 1280, 720, 656, 368, 2, 0.65, 0.25),
+    (720, 1280, 720, 1280, 368, 656, 2, 0.8, 0.15),    # portrait net and display
+    (1920, 1080, 1920, 1080, 1312, 736, 2, 0.8, 0.15), # large net
 ])
 def test_device_preprocess_bit_exact(fw, fh, dw, dh, W, H, N, start, gap):
     import caffe_rtpose_amd as r
@@ -486,6 +531,18 @@ def test_frame_batching_is_transparent(prec_name, B, N):
     (0, 656, 368, 1, 1.0, 0.3, "noise"),        # saturates max_peaks: raster-order cap, thousands of PAF candidates
     (0, 64, 48, 2, 1.0, 0.25, "noise"),         # tiny map: strips shorter than 8 rows, borders everywhere
     (1, 496, 368, 1, 1.0, 0.3, "noise"),
+    # round 5: --start_scale != 1: the strip kernel's low-res row ranges, crops and the bound pre-pass with padw / padh > 0 at scale 0
+    (0, 656, 368, 1, 0.8, 0.15, "noise"),
+    (0, 656, 368, 2, 0.8, 0.15, "noise"),
+    (0, 656, 368, 3, 0.8, 0.15, "speople5"),
+    (0, 656, 368, 1, 0.65, 0.25, "speople5"),    # one scale: the column-skip path on a cropped map
+    (0, 656, 368, 3, 0.65, 0.25, "noise"),       # scale 2 = 0.15: a 14 x 8 crop
+    (1, 496, 368, 2, 0.8, 0.25, "speople5"),
+    (1, 496, 368, 2, 0.65, 0.15, "noise"),
+    (0, 1312, 736, 2, 0.8, 0.15, "noise"),       # large net: 164-column low-res rows, LDS-staged PAF planes do not fit
+    (0, 1312, 736, 1, 0.8, 0.15, "speople5"),
+    (0, 368, 656, 1, 1.0, 0.3, "noise"),         # portrait: the first max_peaks maxima lie in the rows the write kernel's `width` bound keeps
+    (0, 64, 48, 2, 0.7, 0.3, "noise"),
 ])
 def test_fused_postproc_from_lowres_bit_exact(model, W, H, N, start, gap, kind):
     e = _engine(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, frames_in_flight=1)
@@ -495,6 +552,9 @@ def test_fused_postproc_from_lowres_bit_exact(model, W, H, N, start, gap, kind):
     if kind == "noise":
         low = (_synth.smooth_field(N * e.heat_channels, h, w, seed=31, scale=1.0).reshape(N, e.heat_channels, h, w)
                + 0.25 * np.random.default_rng(7).standard_normal((N, e.heat_channels, h, w)).astype(np.float32))
+    elif kind.startswith("speople"):   # the same people at every scale, planted in each scale's crop window
+        import _pincases as pc
+        low = pc.scaled_people(model, tabs, int(kind[7:]), h, w, 44, N, start, gap)
     else:
         low, _ = _synth.people_lowres(model, tabs, int(kind[6:]), h, w, seed=44, N=N)
         low = low.reshape(N, e.heat_channels, h, w)

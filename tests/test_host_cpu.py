@@ -63,6 +63,40 @@ def test_no_cpu_fallback_when_no_device():
     assert b"no CPU fallback" in r.lib.rtp_last_error(None)
 
 
+BAD_GEOMETRY = [dict(start_scale=1.2), dict(start_scale=0.0), dict(start_scale=-0.5), dict(start_scale=float("nan")), dict(start_scale=float("inf")),
+                dict(num_scales=3, start_scale=0.5, scale_gap=0.25),      # third scale = 0: cv::resize to an empty image in the reference
+                dict(num_scales=2, scale_gap=float("nan")), dict(num_scales=2, scale_gap=-0.3),   # second scale 1.3 > 1
+                dict(net_w=650), dict(net_h=100), dict(net_w=0), dict(net_h=-16), dict(num_scales=0), dict(num_scales=17)]
+
+
+def test_out_of_contract_scales_and_net_sizes_are_einval_before_any_device_is_touched():
+    """The reference CHECKs (rtpose.cpp:363-364: target <= net resolution) and dies inside cv::resize for a scale <= 0; the C ABI returns
+    RTP_EINVAL from rtp_engine_create — also where no GPU exists: argument errors come before RTP_ENODEV — and from
+    rtp_preprocess_frame, never a crash or an exception across the boundary."""
+    import caffe_rtpose_amd as r
+    for kw in BAD_GEOMETRY:
+        with pytest.raises(r.RtpError) as ei:
+            r.Engine(r.Config(**{**dict(net_w=160, net_h=96, frames_in_flight=1), **kw}))
+        assert ei.value.code == r.RTP_EINVAL, kw
+    img = np.zeros((48, 64, 3), np.uint8)
+    for kw in BAD_GEOMETRY:
+        a = {**dict(net_w=160, net_h=96, num_scales=1, start_scale=1.0, scale_gap=0.3), **kw}
+        if a["num_scales"] > 16 or a["num_scales"] < 1 or a["net_w"] < 1 or a["net_h"] < 1:
+            continue     # (the ctypes mirror cannot allocate an output for these; the host function has no scale cap of its own)
+        with pytest.raises(r.RtpError) as ei:
+            r.preprocess_frame(img, 320, 180, a["net_w"], a["net_h"], a["num_scales"], a["start_scale"], a["scale_gap"])
+        assert ei.value.code == r.RTP_EINVAL, kw
+    with pytest.raises(r.RtpError):
+        r.preprocess_frame(img, 0, 180, 160, 96)
+    # in contract: --start_scale 0.8 --scale_gap 0.15 --num_scales 3 -> levels 0.8, 0.65, 0.5, each padded into the net input
+    x, _, _ = r.preprocess_frame(np.full((180, 320, 3), 200, np.uint8), 320, 180, 160, 96, 3, 0.8, 0.15)
+    assert x.shape == (3, 3, 96, 160)
+    for i, s in enumerate((0.8, 0.65, 0.5)):
+        tw, th = int(16 * np.ceil(160 * np.float32(s) / 16)), int(16 * np.ceil(96 * np.float32(s) / 16))
+        inside = x[i, 0] != 0
+        assert inside.sum() == tw * th and inside[(96 - th) // 2, (160 - tw) // 2] and not inside[0, 0] or (tw, th) == (160, 96)
+
+
 def test_config_defaults_are_the_reference_flag_defaults():
     # rtpose.cpp:50-72
     import caffe_rtpose_amd as r

@@ -30,7 +30,9 @@ CONFIGS = {  # name -> (model, W, H, num_scales, scale_gap, batch_frames)
     "mpi_1s_b5": (1, 496, 368, 1, 0.3, 5),     # bench.py --model mpi: 240 workgroups of 128x128 tiles per 1/8-resolution launch
     "coco_1s_b2_wseed5": (0, 656, 368, 1, 0.3, 2),   # the split set was chosen on weight seed 1: the tolerance must hold on weights it never saw
     "coco_3s_wseed9": (0, 656, 368, 3, 0.15, 1),
+    "coco_2s_start080": (0, 656, 368, 2, 0.15, 1),   # round 5: --start_scale 0.8 (START below): scales 0.8 and 0.65, both cropped by ImResize
 }
+START = {"coco_2s_start080": 0.8}   # rtp_config.start_scale (rtpose.cpp:68); 1.0 elsewhere
 TOL = {"fp32": 1e-4, "f16x3": 1e-4, "mixed": 1e-3, "fp16": 3e-3}
 _ref_cache = {}
 
@@ -97,14 +99,15 @@ def _explain(lone, res_here, res_other, thr, norm, who):
               f" other side {out[1][1] / norm:+.2e}, {out[1][2] / norm:+.2e}")
 
 
-@pytest.mark.parametrize("mode,cfg", [(m, c) for m in ("mixed", "fp16") for c in CONFIGS if m == "mixed" or c not in SEEDS] +
+@pytest.mark.parametrize("mode,cfg", [(m, c) for m in ("mixed", "fp16") for c in CONFIGS if m == "mixed" or (c not in SEEDS and c not in START)] +
                          [("f16x3", "coco_1s_b1"), ("fp32", "coco_1s_b2")])
 def test_final_maps_and_keypoints_within_tolerance(mode, cfg):
     import caffe_rtpose_amd as r
     model, W, H, N, gap, B = CONFIGS[cfg]
     wseed = SEEDS.get(cfg, 1)
-    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, scale_gap=gap, precision=_prec(r, mode), frames_in_flight=B, batch_frames=B,
-                          synthetic_seed=wseed))
+    start = START.get(cfg, 1.0)
+    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, precision=_prec(r, mode), frames_in_flight=B,
+                          batch_frames=B, synthetic_seed=wseed))
     x, ref = _reference(model, W, H, N, e, wseed)
     # bring the maps into the range real confidences live in: exact power-of-two scaling of the linear branch-final layers
     s = float(2.0 ** -np.ceil(np.log2(np.abs(ref).max())))
@@ -124,7 +127,7 @@ def test_final_maps_and_keypoints_within_tolerance(mode, cfg):
     parts, max_peaks = e.num_parts, e.max_peaks
     thr = e.get_thresholds()["nms_threshold"]
     res_e = e.resize(got)
-    res_r = orc.imresize(ref_s, W, H, 1.0, gap)[0]
+    res_r = orc.imresize(ref_s, W, H, start, gap)[0]
     pk_e = e.nms(res_e)
     pk_r = orc.nms(res_r, parts, max_peaks, thr)
     pairs, na, nb, lone_e, lone_r = _match_peaks(pk_e, pk_r, max_peaks)
@@ -157,7 +160,7 @@ def _bench_module():
     return m
 
 
-@pytest.mark.parametrize("cfg", ["coco_1s_b2", "coco_3s_b2", "mpi_1s_b5"])
+@pytest.mark.parametrize("cfg", ["coco_1s_b2", "coco_3s_b2", "mpi_1s_b5", "coco_2s_start080"])
 def test_people_level_parity_of_the_benched_mode(cfg):
     """SURVEY section 7 / BASELINE.md section 3 on the configurations bench.py quotes: the engine's joints in the DEFAULT (mixed) mode
     through rtp_submit / rtp_collect vs the full fp32 oracle chain (conv -> ImResize -> Nms -> connectLimbs*), compared as sets of
@@ -170,9 +173,11 @@ def test_people_level_parity_of_the_benched_mode(cfg):
     import caffe_rtpose_amd as r
     bench = _bench_module()
     model, W, H, N, gap, B = CONFIGS[cfg]
-    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, scale_gap=gap, precision=r.PREC_MIXED, frames_in_flight=2 * B, batch_frames=B))
+    start = START.get(cfg, 1.0)
+    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, precision=r.PREC_MIXED, frames_in_flight=2 * B,
+                          batch_frames=B))
     x, ref = _reference(model, W, H, N, e)
-    rep = bench.parity_report(e, [(x, ref, 0.0)], "coco" if model == 0 else "mpi", N, gap)
+    rep = bench.parity_report(e, [(x, ref, 0.0)], "coco" if model == 0 else "mpi", N, gap, start_scale=start)
     print(f"\n[parity {cfg}] " + ", ".join(f"{k}: {v}" for k, v in rep.items() if k not in ("structured", "units", "reference")))
     print(f"[parity {cfg}] structured: {rep['structured']}")
     assert rep["verdict"].startswith(("pass", "numeric pass")), rep["verdict"]
@@ -185,8 +190,11 @@ def test_people_level_parity_of_the_benched_mode(cfg):
     # The random-weight network's maps are noise: hundreds of maxima, some of them near-ties.  Each flip re-numbers the raster-ordered
     # peaks of its part and re-routes connectLimbs' greedy picks, so a few PEOPLE differ structurally although every corresponding joint
     # agrees to a few hundredths of a pixel; the floor below only guards against a silent collapse of the comparison itself.
-    assert rep["people_ref"] > (20 if model == 0 else 5) and rep["joints_matched"] >= 0.8 * rep["joints_ref"]
-    assert rep["people_matched"] >= 0.6 * rep["people_ref"]
+    # (measured in round 4: 61 of 77 / 38 of 47 / 13 of 13 people, 324 of 348 / 144 of 158 / 45 of 45 joints)
+    # round 5, --start_scale 0.8 at 2 scales: 20 of 30 people, 95 of 111 joints (fewer, larger maxima per map: one flip moves more)
+    fj, fp = (0.8, 0.6) if cfg in START else (0.85, 0.7)
+    assert rep["people_ref"] > (20 if model == 0 else 5) and rep["joints_matched"] >= fj * rep["joints_ref"]
+    assert rep["people_matched"] >= fp * rep["people_ref"]
     st = rep["structured"]
     assert st["verdict"].startswith("pass"), st
     assert all(c["identical_within_one_net_pixel"] and c["numeric_out_of_tol"] == 0 and c["people_ref"] == c["people_engine"] >= 1 for c in st["cases"].values())

@@ -367,6 +367,13 @@ GEOMS = [  # (frame w, h, display w, h, net w, h, scales, start, gap)
     (500, 375, 640, 360, 320, 176, 1, 1.0, 0.3),       # portrait-ish frame: right part of the display stays black
     (333, 500, 1312, 736, 656, 368, 1, 1.0, 0.3),      # display = 2x the net: resizeAreaFast_ 2x2
     (320, 240, 960, 528, 320, 176, 1, 1.0, 0.3),       # display = 3x the net: resizeAreaFast_ general
+    # round 5: --start_scale != 1 (rtpose.cpp:68, 353-368: s = start_scale - i gap for EVERY level incl. the first), portrait, large
+    (1280, 720, 1280, 720, 656, 368, 1, 0.8, 0.15),    # 528x304 inside 656x368: the first level is padded too
+    (1280, 720, 1280, 720, 656, 368, 3, 0.8, 0.15),    # 0.8, 0.65, 0.5 (the last one: 1280 / 336, 720 / 192 — table path)
+    (1920, 1080, 1280, 720, 656, 368, 2, 0.65, 0.25),  # 0.65, 0.4
+    (720, 1280, 720, 1280, 368, 656, 2, 0.8, 0.15),    # portrait frame, display and net
+    (1920, 1080, 1920, 1080, 1312, 736, 2, 0.8, 0.15), # large net (low-res 92 x 164)
+    (1312, 736, 1312, 736, 656, 368, 2, 0.5, 0.25),    # display = 4x / 8x the target: resizeAreaFast_ at start_scale 0.5
 ]
 
 

@@ -44,10 +44,10 @@ def test_oracle_reproduces_the_reference_outputs():
     for m in (0, 1):
         assert orc.model_tables(m) == tables[m]
     for name, (model, low, W, H, start, gap) in pc.lowres_cases(tables).items():
-        res, peaks, n, joints = pc.chain(orc, model, low, W, H, start, gap)
+        res, peaks, n, joints = pc.chain(orc, model, low, W, H, start, gap, pc.disp_of(name))
         assert pc.digest(res) == _sha(f"chain_{name}_resized_sha"), name
-        assert np.array_equal(peaks, G[f"chain_{name}_peaks"]), name
-        assert np.array_equal(joints, G[f"chain_{name}_joints"]), name
+        assert np.array_equal(peaks, G[f"chain_{name}_peaks"], equal_nan=True), name
+        assert n == int(G[f"chain_{name}_count"][0]) and np.array_equal(joints, G[f"chain_{name}_joints"]), name
     for nm, (res, peaks) in (("ties", pc.tie_case()), ("single", pc.single_sided_case())):
         n, joints = orc.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
         assert np.array_equal(joints[:n], G[f"connect_{nm}_joints"])
@@ -77,25 +77,38 @@ def test_host_library_reproduces_the_reference_outputs():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["coco_noise_1s", "coco_noise_3s", "mpi_noise_1s", "small_noise_2s", "coco_people1", "coco_people5",
-                                  "coco_people20", "coco_people5_3s", "mpi_people5"])
+                                  "coco_people20", "coco_people5_3s", "mpi_people5"] + pc.ROUND5_CASES)
 def test_engine_reproduces_the_reference_outputs(name):
+    """Round 5 adds --start_scale 0.8 / 0.65 at 1-3 scales (the crop of scale 0 moves too, imresize_layer.cu:110-113), a portrait and a
+    1312x736 net, MPI, and display resolutions other than 1280x720 in connect's output scaling (rtpose.cpp:1051-1073)."""
     import caffe_rtpose_amd as r
     model, low, W, H, start, gap = pc.lowres_cases(_tables())[name]
     N = low.shape[0]
-    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, frames_in_flight=1))
+    dw, dh = pc.disp_of(name)
+    e = r.Engine(r.Config(model=model, net_w=W, net_h=H, num_scales=N, start_scale=start, scale_gap=gap, disp_w=dw, disp_h=dh, frames_in_flight=1))
     low = np.ascontiguousarray(low, np.float32)
-    want_peaks, want_joints = G[f"chain_{name}_peaks"], G[f"chain_{name}_joints"]
+    want_peaks, want_joints, want_n = G[f"chain_{name}_peaks"], G[f"chain_{name}_joints"], int(G[f"chain_{name}_count"][0])
     # taps through the materialised map (the reference's own dataflow)
     res = e.resize(low)
-    assert pc.digest(res) == _sha(f"chain_{name}_resized_sha")
     assert np.array_equal(res.reshape(-1)[::997], G[f"chain_{name}_resized_sample"])
+    assert pc.digest(res) == _sha(f"chain_{name}_resized_sha")
     peaks = e.nms(res)
-    assert np.array_equal(peaks, want_peaks)
+    assert np.array_equal(peaks, want_peaks, equal_nan=True)
+    if want_n < 0:
+        # the reference CHECK-fails in connect (portrait net: NaN centroids, see _pincases.chain): RTP_ERANGE on every path, never a crash
+        with pytest.raises(r.RtpError) as ei:
+            e.connect(res, peaks)
+        assert ei.value.code == r.RTP_ERANGE
+        with pytest.raises(r.RtpError) as ei:
+            e.post_from_lowres(low)
+        assert ei.value.code == r.RTP_ERANGE
+        e.close()
+        return
     n, joints = e.connect(res, peaks)
-    assert n == len(want_joints) and np.array_equal(joints[:n], want_joints)
+    assert n == want_n and np.array_equal(joints[:n], want_joints)
     # production path: peaks and PAF samples straight from the low-res maps
     p2, j2, n2 = e.post_from_lowres(low)
-    assert np.array_equal(p2, want_peaks) and n2 == len(want_joints) and np.array_equal(j2, want_joints)
+    assert np.array_equal(p2, want_peaks) and n2 == want_n and np.array_equal(j2, want_joints)
     e.close()
 
 

@@ -35,13 +35,16 @@ def tables():
 def test_imresize_nms_connect_chain_bit_equal(tables):
     """noise maps (peaks saturate max_peaks), planted people 1/5/20, COCO + MPI, 1-3 scales: every stage output equal."""
     for name, (model, low, W, H, start, gap) in pc.lowres_cases(tables).items():
-        a = pc.chain(orc, model, low, W, H, start, gap)
-        b = pc.chain(_ref, model, low, W, H, start, gap)
+        a = pc.chain(orc, model, low, W, H, start, gap, pc.disp_of(name))
+        b = pc.chain(_ref, model, low, W, H, start, gap, pc.disp_of(name))
         assert np.array_equal(a[0], b[0]), f"{name}: ImResize differs"
-        assert np.array_equal(a[1], b[1]), f"{name}: Nms differs"
+        assert np.array_equal(a[1], b[1], equal_nan=True), f"{name}: Nms differs"
         assert a[2] == b[2] and np.array_equal(a[3], b[3]), f"{name}: connect differs ({a[2]} vs {b[2]} people)"
-        if "people" in name:
+        if "people" in name and name != "portrait_people3_s080_n2":
             assert a[2] >= 1, name
+    # a net taller than wide: peaks below row `width` + 3 get NaN centroids (nms_layer.cu:79 bounds rows by width) and connect aborts
+    a = pc.chain(_ref, *pc.lowres_cases(tables)["portrait_people3_s080_n2"], pc.disp_of("portrait_people3_s080_n2"))
+    assert a[2] == -1 and np.isnan(a[1][:, 1:, :2]).any()
 
 
 def test_nms_stale_slots_and_count_semantics(tables):

@@ -20,11 +20,12 @@ tables = {m: _ref.model_tables(m) for m in (0, 1)}
 for m in (0, 1):
     out[f"tables_{m}"] = np.array([tables[m][0], tables[m][1]] + tables[m][2] + tables[m][3], np.int32)
 for name, (model, low, W, H, start, gap) in pc.lowres_cases(tables).items():
-    res, peaks, n, joints = pc.chain(_ref, model, low, W, H, start, gap)
+    res, peaks, n, joints = pc.chain(_ref, model, low, W, H, start, gap, pc.disp_of(name))
     out[f"chain_{name}_resized_sha"] = np.frombuffer(pc.digest(res).encode(), np.uint8)
     out[f"chain_{name}_resized_sample"] = res.reshape(-1)[::997].copy()
     out[f"chain_{name}_peaks"] = peaks
     out[f"chain_{name}_joints"] = joints
+    out[f"chain_{name}_count"] = np.array([n], np.int32)     # -1: the reference CHECK-fails in connect (portrait net, _pincases.chain)
     print(f"{name}: {n} people, peak totals max {int(peaks[:, 0, 0].max())}")
 for nm, (res, peaks) in (("ties", pc.tie_case()), ("single", pc.single_sided_case())):
     n, joints = _ref.connect(0, res, peaks, 64, 656, 368, 1280, 720, pc.THR[0])
