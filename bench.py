@@ -214,7 +214,11 @@ def parity_report(eng, fr, model, num_scales, scale_gap, structured=True, start_
     tot["map_max_err"] = map_err
     tot["post_on_engine_maps_bit_exact"] = bool(post_exact)
     tot["structural_explained"] = ex["structural_explained"]
-    tot["explain"] = {k: ex[k] for k in ("root_flips", "unexplained", "unexplained_detail", "attribution", "e_map", "e_pos_net_px", "worst_margin_over_allowance")}
+    tot["explain"] = {k: ex[k] for k in ("root_flips", "unexplained", "unexplained_detail", "attribution", "e_map", "e_pos_net_px", "worst_margin_over_allowance",
+                                         "replay_forced", "replay_unexplained", "replay_unexplained_detail", "replay_worst_margin_over_allowance")}
+    # the per-joint proof (tests/_replay.py): the reference side replayed with the engine's outcome forced at every decision that differs for the
+    # same inputs — each a checked near-tie — gives the engine's people exactly
+    tot["replay_identical"] = bool(ex["replay_identical"] and ex["replay_unexplained"] == 0)
     tot["units"] = "x, y in display pixels (1280x720); scores and map errors for maps normalised to a maximum of 1; explain.e_map in raw map units"
     tot["reference"] = "CPU oracle, fp32 conv stack -> ImResize -> Nms -> connectLimbs*, same synthetic weights and frames"
     tot["verdict"] = _parity.verdict(tot, map_err=map_err, post_exact=post_exact, explained=ex["structural_explained"] if ex["unexplained"] == 0 else 0)
@@ -345,6 +349,94 @@ def roofline_block(dom_ms, dom_n, dom_flops, byp, solo_ms, peak, tr=None, tr2=No
         roof["solo"] = {"ms_per_launch": solo_ms, "achieved": dom_flops / (solo_ms * 1e-3) / 1e12, "frac": dom_flops / (solo_ms * 1e-3) / peak,
                         "what": "the plain fp16 instantiation, 200 launches back to back between two events"}
     return roof
+
+
+def kernel_classes(plan_lines, layers, step_times, net_w, net_h, images_per_launch, peak):
+    """`roofline.classes`: the per-step HIP-event timings of the roofline pass (rtp_kernel_timing 3: one pair around EVERY launch of a full
+    batch, one batch at a time) grouped by kernel class.  plan_lines: the "step ..." lines of rtp_plan_summary (same order as step_times);
+    layers: [(name, cin, cout, k)].  Algorithmic FLOPs per launch = sum over the step's layers of 2 Cout Cin k^2 H W x images per launch
+    (SURVEY 8a3's formula; H x W of the layer's resolution level).  Per class: launches timed, average us per launch, ms per batch (the
+    class's launches of ONE batch), algorithmic TFLOP/s over the class's time, fraction of the fp16 MFMA peak, share of the batch's summed
+    launch time."""
+    dims = {n: (cin, cout, k) for n, cin, cout, k in layers}
+
+    def level(name):
+        return 0 if name.startswith("conv1_") else 1 if name.startswith("conv2_") else 2 if name.startswith("conv3_") else 3
+
+    rows, order = {}, []
+    for ln, (ms, n) in zip(plan_lines, step_times):
+        m = re.match(r"step (\w+) (.*?) k (\d+) ", ln)
+        if not m or n == 0:
+            continue
+        kind, k = m.group(1), int(m.group(3))
+        names = [t for t in re.findall(r"[A-Za-z0-9_]+", m.group(2)) if t in dims]
+        flops = sum(2.0 * dims[t][1] * dims[t][0] * dims[t][2] ** 2 * (net_h >> level(t)) * (net_w >> level(t)) for t in names) * images_per_launch
+        q = "2q" if " passes 2q " in ln else "3 passes" if re.search(r" passes 3\w* ", ln) and kind == "conv" else "plain"
+        n0 = names[0] if names else ""
+        if kind == "first":
+            cls = "conv1_1 (conv_first)"
+        elif kind == "pw2":
+            cls = "branch tails 1x1->1x1 (conv_pw2)"
+        elif kind == "conv" and k == 7:
+            cls = ("dominant 7x7 128->128 pair " if dims[n0][0] == 128 else f"stage-entry 7x7 {dims[n0][0]}->128 pair ") + q
+        elif kind == "conv" and n0.startswith(("conv1_", "conv2_", "conv3_", "conv4_")):
+            cls = "trunk 3x3 " + q
+        elif kind == "conv":
+            cls = f"stage-1 {k}x{k} pair " + q
+        else:
+            cls = kind
+        if cls not in rows:
+            rows[cls] = {"steps": 0, "launches": 0, "ms": 0.0, "ms_per_batch": 0.0, "flops": 0.0}
+            order.append(cls)
+        r_ = rows[cls]
+        r_["steps"] += 1
+        r_["launches"] += n
+        r_["ms"] += ms
+        r_["ms_per_batch"] += ms / n
+        r_["flops"] += flops * n
+    total = sum(r_["ms_per_batch"] for r_ in rows.values()) or 1.0
+    out = {}
+    for cls in order:
+        r_ = rows[cls]
+        tf = r_["flops"] / (r_["ms"] * 1e-3) / 1e12 if r_["ms"] > 0 else 0.0
+        out[cls] = {"steps_per_batch": r_["steps"], "launches_timed": r_["launches"], "us_per_launch": r_["ms"] / r_["launches"] * 1e3,
+                    "ms_per_batch": r_["ms_per_batch"], "tflops": tf, "frac_of_peak": tf * 1e12 / peak, "share_of_batch": r_["ms_per_batch"] / total}
+    return out, total
+
+
+def busy_account(spans):
+    """rtp_busy_probe's spans -> the share of the wall (first start .. last end, after dropping the first tenth as warm-up) in which the
+    engine had work on the GPU: union of every batch's conv-stream span (first input staging .. end of its conv stack) and every frame's
+    post-processing chain.  No profiler attached: the events are the ones the per-frame path records anyway."""
+    import numpy as np
+    if len(spans) < 8:
+        return None
+    sp = spans[np.argsort(spans[:, 1])]
+    sp = sp[len(sp) // 10:]
+    lo, hi = float(sp[:, 1].min()), float(sp[:, 2].max())
+
+    def union(a):
+        tot, cur_s, cur_e = 0.0, None, None
+        for s_, e_ in a:
+            if cur_e is None or s_ > cur_e:
+                if cur_e is not None:
+                    tot += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        return tot + (cur_e - cur_s if cur_e is not None else 0.0)
+
+    allu = union(sp[:, 1:3].tolist())
+    conv = sp[sp[:, 0] == 0]
+    post = sp[sp[:, 0] == 1]
+    wall = max(hi - lo, 1e-9)
+    return {"busy_frac": allu / wall, "idle_frac": 1.0 - allu / wall, "conv_streams_busy_frac": union(conv[:, 1:3].tolist()) / wall if len(conv) else None,
+            "post_chains_busy_frac": union(post[:, 1:3].tolist()) / wall if len(post) else None,
+            "conv_stacks_concurrent_avg": float((conv[:, 2] - conv[:, 1]).sum() / wall) if len(conv) else None,
+            "window_ms": wall, "spans": int(len(sp)),
+            "what": "UNPROFILED: union of per-stream busy spans (HIP events of the pipelined run: each batch from its first input staging to the end of its conv stack "
+                    "on the batch's stream, each frame's post-processing chain + D2H on its own stream) over the wall between the first start and the last end; "
+                    "idle_frac = no stream of the engine had anything to run (rocprofv3's timeline of the same loop: profiles/, carries the tracer's overhead)"}
 
 
 def respawn_under_launcher(args):
@@ -559,7 +651,7 @@ def main():
         dominant-class launch, recorded on the stream the launch runs on (rtp_kernel_timing; batches are launched eagerly while it is on).
         No other frame's kernels are on the chip, so a pair brackets that launch alone inside whole frames (real layer sequence, real L2
         state): the quantity a rocprofv3 kernel trace averages (profiles/).  Nothing compares clocks of different XCDs."""
-        eng.kernel_timing(2)
+        eng.kernel_timing(3)        # an event pair around EVERY step of a full batch; the dominant class's totals keep their meaning
         nb = max(1, batch_frames)
         for b in range(40):
             for j in range(nb):
@@ -568,18 +660,32 @@ def main():
                 eng.collect()
         dom_ms, dom_n, dom_flops = eng.kernel_timing(-1)
         byp = eng.kernel_timing_by_passes()
+        steps_t = eng.kernel_timing_steps()
         eng.kernel_timing(0)
         peak = 157.3e12 if precision == "fp32" else 2.5e15
         solo_ms, _ = eng.bench_dominant_conv(iters=200)   # the plain instantiation back to back, alone on the chip (HIP events around 200 launches)
-        return roofline_block(dom_ms, dom_n, dom_flops, byp, solo_ms, peak, pmc_traffic(precision, batch_frames, num_scales, model),
+        roof = roofline_block(dom_ms, dom_n, dom_flops, byp, solo_ms, peak, pmc_traffic(precision, batch_frames, num_scales, model),
                               pmc_traffic(precision, batch_frames, num_scales, model, "_2q"))
+        try:
+            plan = [ln for ln in r.plan_summary(eng.cfg).splitlines() if ln.startswith("step ")]
+            if len(plan) == len(steps_t):
+                classes, total = kernel_classes(plan, eng.conv_layers(), steps_t, eng.net_w, eng.net_h, nb * num_scales, peak)
+                roof["classes"] = classes
+                roof["batch_ms_sum_of_launches"] = total
+                for cls, row in classes.items():   # flat scalars too: a record that keeps only one level of `roofline` still shows them
+                    key = "cls_" + re.sub(r"[^a-z0-9]+", "_", cls.lower()).strip("_")
+                    roof[key + "_us"] = round(row["us_per_launch"], 2)
+                    roof[key + "_tflops"] = round(row["tflops"], 1)
+        except Exception as ex:  # noqa: BLE001
+            roof["classes_error"] = str(ex)
+        return roof
 
     mid, W, H, _, _, _, gflop = MODELS[args.model]
     eng = make_engine(args.precision, args.num_scales, args.scale_gap, args.batch_frames, args.in_flight)
     wb = None
     if dist is not None and args.broadcast_weights:   # one-time: every rank ends up with rank 0's packed arena (outside the timed region)
         t0 = time.perf_counter()
-        blob = eng.weight_blob() if rank == 0 else np.zeros(len(eng.weight_blob()), np.uint8)
+        blob = eng.weight_blob() if rank == 0 else np.zeros(eng.weight_blob_bytes(), np.uint8)   # (non-zero ranks only need the length: no D2H copy)
         blob = broadcast_bytes(blob, 0, dist, red_dev)
         if rank != 0:
             eng.load_weight_blob(blob)
@@ -601,6 +707,17 @@ def main():
     # Roofline pass (separate from the timed region, which runs un-instrumented)
     roof = roofline_pass(eng, frames, args.batch_frames, args.precision, args.num_scales, args.model)
     stage = eng.last_stage_ms()
+    busy = None
+    if rank == 0:   # the same pipelined loop once more with the busy probe on (~0.5 s): when did the engine have work on the GPU — no profiler attached
+        try:
+            eng.busy_probe(1)
+            mb = measure(eng, submit, 200, 20, args.in_flight, 0.5)
+            busy = busy_account(eng.busy_probe(-1))
+            eng.busy_probe(0)
+            if busy:
+                busy["frames_per_s_with_probe"] = mb["fps"] * (1 if world == 1 else 1.0 / world)
+        except Exception as ex:  # noqa: BLE001
+            busy = {"error": str(ex)}
 
     if rank == 0:
         # dominant kernel: the paired 7x7 128->128 convolution (40 of the 92 layers, 50% of all FLOPs).  Average launch duration over
@@ -627,8 +744,10 @@ def main():
                        "parallelism": f"frame-sharded replicas x{world}"},
             "latency_ms": {"p50_pipelined": float(np.percentile(m["lat"], 50) * 1e3), "p95_pipelined": float(np.percentile(m["lat"], 95) * 1e3),
                            "batch_on_device": stage["total"]},
-            "host_ms_per_frame": m["host_ms"], "roofline": roof, "conv_stack_whole_frame": whole,
+            "host_ms_per_frame": m["host_ms"], "roofline": roof, "conv_stack_whole_frame": whole, "gpu_busy": busy,
         }
+        if busy and "busy_frac" in busy:
+            roof["gpu_busy_frac_unprofiled"] = round(busy["busy_frac"], 4)
         if args.precision == "mixed":
             out["config"]["split_layers"] = eng.split_layers()[0]
             if args.calibrate:
@@ -669,6 +788,30 @@ def main():
                     out["parity"] = parity_report(eng, orc_fr[1][1:], args.model, args.num_scales, args.scale_gap)
                 except Exception as ex:  # noqa: BLE001
                     out["parity"] = {"error": str(ex), "verdict": f"FAIL: {ex}"}
+        # A compact summary of every leg: the LAST key of the line (a truncated tail still shows it) and, as flat scalars, inside `roofline`
+        # (records that keep `roofline` but not `sub_results` still show every leg's headline number).
+        sr = out.get("sub_results") or {}
+
+        def g(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+
+        rnd = lambda v, n=1: None if v is None else round(float(v), n)   # noqa: E731
+        summ = {"fps": rnd(fps), "p50_single_frame_ms": rnd(g(out, "latency_ms", "p50_single_frame"), 3), "p50_pipelined_ms": rnd(g(out, "latency_ms", "p50_pipelined"), 2),
+                "dominant_frac": rnd(roof.get("frac"), 4), "resident_fps": rnd(g(sr, "resident_input", "value")),
+                "scales3_fps": rnd(g(sr, "scales3_gap0.15", "value")), "scales3_p50_ms": rnd(g(sr, "scales3_gap0.15", "p50_ms"), 2),
+                "scales3_dominant_frac": rnd(g(sr, "scales3_gap0.15", "roofline", "frac"), 4),
+                "mpi_fps": rnd(g(sr, "mpi_496x368", "value")), "mpi_dominant_frac": rnd(g(sr, "mpi_496x368", "roofline", "frac"), 4),
+                "fp16_fps": rnd(g(sr, "precision_fp16_single_pass", "value")), "fp32_fps": rnd(g(sr, "precision_fp32", "value")),
+                "cpu_fps": rnd(g(out, "cpu_baseline", "value"), 3), "gpu_busy_frac": rnd(g(out, "gpu_busy", "busy_frac"), 4),
+                "parity": (g(out, "parity", "verdict") or "")[:40], "parity_replay_identical": g(out, "parity", "replay_identical"),
+                "parity_scales3": (g(sr, "scales3_gap0.15", "parity", "verdict") or "")[:40], "parity_mpi": (g(sr, "mpi_496x368", "parity", "verdict") or "")[:40],
+                "classes_us_tflops": {k: [round(v["us_per_launch"], 1), round(v["tflops"])] for k, v in (roof.get("classes") or {}).items()}}
+        for k, v in summ.items():
+            if k != "classes_us_tflops" and v is not None:
+                roof["leg_" + k] = v
+        out["summary"] = summ
         print(json.dumps(out))
     eng.close()
     if dist is not None:
@@ -743,7 +886,8 @@ def sub_results(args, r, eng, make_engine, device_frames, host_frames, measure, 
             m = measure(e3, lambda i, tag: e3.submit_frame(u8[i % 8], tag=tag), in_flight=3, **short)
             peak = 157.3e12 if args.precision == "fp32" else 2.5e15
             res["scales3_gap0.15"] = {"value": m["fps"], "unit": "frames/s", "steps_timed": m["steps_timed"], "p50_ms": float(np.percentile(m["lat"], 50) * 1e3),
-                                      "conv_stack_frac_of_peak": m["fps"] * gflop * 3e9 / peak, "batch_frames": 1, "frames_in_flight": 3, "input": "host_u8"}
+                                      "conv_stack_frac_of_peak": m["fps"] * gflop * 3e9 / peak, "batch_frames": 1, "frames_in_flight": 3, "input": "host_u8",
+                                      "roofline": roofline_pass(e3, device_frames(e3), 1, args.precision, 3, args.model)}   # the north-star target configuration's own plan (186-workgroup launches)
             if not args.no_parity:
                 try:
                     res["scales3_gap0.15"]["parity"] = parity_report(e3, oracle_frames(e3, 3, args.model, 0, seed0=7)[1], args.model, 3, 0.15, structured=False)

@@ -55,6 +55,8 @@ SIGNATURES = {
     "rtp_set_scales": (C.c_int, [vp, C.c_float, C.c_float]),
     "rtp_debug_f32_to_e4m3": (C.c_int, [fp, C.POINTER(C.c_ubyte), C.c_int]),
     "rtp_kernel_timing_by_passes": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "rtp_kernel_timing_steps": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
+    "rtp_busy_probe": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "rtp_submit": (C.c_int, [vp, fp, C.c_uint64]),
     "rtp_submit_device": (C.c_int, [vp, vp, C.c_uint64]),
     "rtp_submit_frame": (C.c_int, [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_uint64, fp]),

@@ -165,6 +165,8 @@ struct Ctx {
   // per (timed?, frames in the batch) and replayed; gev = {before, after} the replay on `stream`
   hipGraphExec_t gexec[17] = {};
   hipEvent_t gev[2] = {nullptr, nullptr};
+  hipEvent_t ev_stage0 = nullptr;         // rtp_busy_probe: recorded in front of the batch's first input staging
+  bool stage0_set = false;
   bool graph_run = false;                 // the batch in flight was ONE graph replay incl. post-processing (collect waits on gev[1])
   bool graph_conv = false;                // the conv stack was a replay, the post-processing chains were launched eagerly
 };
@@ -181,6 +183,8 @@ struct rtp_engine {
   float nms_threshold = 0.05f, inter_threshold = 0.05f, min_subset_score = 0.4f;
   int inter_min_above = 9, min_subset_cnt = 3;
   float start_scale = 1.f, scale_gap = 0.3f;
+  bool calib_fell_back = false;   // rtp_calibrate_precision ended in RTP_PREC_F16X3 (its last resort)
+  bool broken = false;   // a re-plan failed and the previous plan could not be restored: no contexts; every entry point fails, destroy works
   int N = 1;    // images per frame (num_scales)
   int B = 1;    // frames per batch (cfg.batch_frames)
   int NI = 1;   // images per conv launch at a full batch = N * B
@@ -213,6 +217,16 @@ struct rtp_engine {
   // launched eagerly while it is on).  Nothing here compares clocks of different XCDs.
   std::vector<hipEvent_t> tev;            // 2 * pairs
   std::vector<unsigned char> tev_pass;    // MFMA passes (1..3) of the launch behind pair i
+  std::vector<short> tev_step;            // plan step of the launch behind pair i
+  // rtp_busy_probe: when on, every batch's stream-busy spans (first input staging .. end of its conv stack on the batch's stream; start ..
+  // end of each frame's post-processing chain incl. the D2H of the joints on the frame's stream) are read back at collect time as
+  // milliseconds since `busy_base` — an UNPROFILED account of when the engine had work on the GPU (bench.py: gpu_busy)
+  bool busy_probe = false;
+  hipEvent_t busy_base = nullptr;
+  std::vector<float> busy_spans;          // [n][3]: kind (0 conv stream, 1 post chain), start ms, end ms
+  bool time_all = false;                  // rtp_kernel_timing(3): an event pair around EVERY step of a full batch, not only the dominant class
+  std::vector<double> step_ms;            // per plan step: event-timed milliseconds / launches of the timing pass (rtp_kernel_timing_steps)
+  std::vector<long> step_n;
   int tev_next = 0;
   static const int TEV_PAIRS = 4096;
   // device-side pre-processing (row a1)
@@ -1137,20 +1151,27 @@ int launch_first_step(rtp_engine* e, Ctx& cx, const Step& s, const float* input_
 int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bool cap = false) {
   const std::vector<PoolOp>& pools = e->pools;
   auto geom_n = [&](int level) { Geom g = e->geom[level]; g.N = nimg; return g; };
-  for (auto& s : e->steps) {
+  for (size_t si = 0; si < e->steps.size(); ++si) {
+    const Step& s = e->steps[si];
+    // timing pass: an event pair on this stream around the launch (full batches only: the FLOP count reported is the full batch's);
+    // the dominant class only (rtp_kernel_timing 1 / 2) or every step of the plan (3: bench.py's roofline.classes)
+    const bool timed = e->time_dominant && !cap && nimg == e->NI && (e->time_all || is_dominant_class(e, s)) && e->tev_next < (int)e->tev.size() / 2;
+    if (timed) HIPCHK(e, hipEventRecord(e->tev[2 * (size_t)e->tev_next], cx.stream));
+    struct Close {   // second event + bookkeeping on every way out of the step's branch
+      rtp_engine* e; Ctx& cx; const Step& s; size_t si; bool timed;
+      ~Close() {
+        if (!timed) return;
+        (void)hipEventRecord(e->tev[2 * (size_t)e->tev_next + 1], cx.stream);
+        e->tev_step[e->tev_next] = (short)si;
+        e->tev_pass[e->tev_next++] = (unsigned char)(s.type == 1 ? e->convs[s.a].passes() : 1);
+      }
+    } close_{e, cx, s, si, timed};
     if (s.type == 0) {
       const Tensor& t = e->tensors[0];
       HIPCHK(e, launch_pack_input(e->prec, input_dev, cx.arena + t.offset, geom_n(0), t.stride(), cx.stream));
     } else if (s.type == 1) {
-      // timing pass: an event pair on this stream around the launch (full batches only: the FLOP count reported is the full batch's)
-      const bool timed = e->time_dominant && !cap && nimg == e->NI && is_dominant_class(e, s) && e->tev_next < (int)e->tev.size() / 2;
-      if (timed) HIPCHK(e, hipEventRecord(e->tev[2 * (size_t)e->tev_next], cx.stream));
       const int rc = launch_conv_step(e, cx, s, nimg);
       if (rc) return rc;
-      if (timed) {
-        HIPCHK(e, hipEventRecord(e->tev[2 * (size_t)e->tev_next + 1], cx.stream));
-        e->tev_pass[e->tev_next++] = (unsigned char)e->convs[s.a].passes();
-      }
     } else if (s.type == 3) {
       const int rc = launch_pw2_step(e, cx, s, nimg);
       if (rc) return rc;
@@ -1477,12 +1498,14 @@ void free_ctx(Ctx& cx) {
   if (cx.host_in) (void)hipHostFree(cx.host_in);
   for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
   for (int i = 0; i < 2; ++i) if (cx.gev[i]) (void)hipEventDestroy(cx.gev[i]);
+  if (cx.ev_stage0) { (void)hipEventDestroy(cx.ev_stage0); cx.ev_stage0 = nullptr; }
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
   if (cx.spare_stream) (void)hipStreamDestroy(cx.spare_stream);
   cx = Ctx();
 }
 
 int use_device(rtp_engine* e) {
+  if (e->broken) return fail(e, RTP_EHIP, "this engine lost its plan in a failed re-plan and can only be destroyed");
   HIPCHK(e, hipSetDevice(e->cfg.device_id));
   return RTP_OK;
 }
@@ -1657,9 +1680,10 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
       if (s != hipSuccess) return fail(e, RTP_EHIP, "dry run failed: %s", hipGetErrorString(s));
     }
   }
-  if (capture && e->use_graph && !e->cfg.render)  // capture the full-batch plan of every context now, not inside the first frames
-    for (auto& c : e->ctx)
-      if ((rc = capture_batch(e, c, e->B, &c.gexec[e->B]))) return rc;
+  if (capture && e->use_graph && !e->cfg.render)  // capture the plan of every context now — the full batch AND the partial batches a flush /
+    for (auto& c : e->ctx)                        // collect can launch — so that the per-frame path never captures (never takes g_sync_mutex)
+      for (int nf = e->B; nf >= 1; --nf)
+        if ((rc = capture_batch(e, c, nf, &c.gexec[nf]))) return rc;
   return RTP_OK;
 }
 
@@ -1688,6 +1712,13 @@ int replan(rtp_engine* e, int mode, const std::string& rules, bool light) {
   int rc = build_plan(e);
   if (rc) return rc;
   return materialize_plan(e, light ? 1 : e->nctx_full, !light);
+}
+
+int busy_mark_stage0(rtp_engine* e, Ctx& cx) {
+  if (!cx.ev_stage0) HIPCHK(e, hipEventCreate(&cx.ev_stage0));
+  HIPCHK(e, hipEventRecord(cx.ev_stage0, cx.in_stream));
+  cx.stage0_set = true;
+  return RTP_OK;
 }
 
 // ---- batching: frames are staged into the open context; a full batch is launched at once ----------
@@ -1791,6 +1822,7 @@ void rtp_engine_destroy(rtp_engine* e) {
   if (e->dweights) (void)hipFree(e->dweights);
   if (e->dchmap) (void)hipFree(e->dchmap);
   for (hipEvent_t ev : e->tev) if (ev) (void)hipEventDestroy(ev);
+  if (e->busy_base) (void)hipEventDestroy(e->busy_base);
   if (e->prep_tables) (void)hipFree(e->prep_tables);
   if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
   for (void* p : e->user_bufs) if (p) (void)hipFree(p);
@@ -1814,6 +1846,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (!cfg || !out) return fail(nullptr, RTP_EINVAL, "null argument");
   *out = nullptr;
   if (cfg->num_scales < 1 || cfg->num_scales > 16) return fail(nullptr, RTP_EINVAL, "num_scales %d out of range", cfg->num_scales);
+  if (cfg->calibrate_frames < -1 || cfg->calibrate_frames > 64) return fail(nullptr, RTP_EINVAL, "calibrate_frames %d out of range [-1, 64]", cfg->calibrate_frames);
   if (cfg->frames_in_flight < 1 || cfg->frames_in_flight > 64) return fail(nullptr, RTP_EINVAL, "frames_in_flight %d out of range", cfg->frames_in_flight);
   if (cfg->batch_frames < 0 || cfg->batch_frames > 16) return fail(nullptr, RTP_EINVAL, "batch_frames %d out of range", cfg->batch_frames);
   {  // render = 1 + part_to_show: the view must stay inside the model's maps (44 MPI: parts + background + 28 PAFs; COCO: 18 parts, "all", 20 PAF views)
@@ -1920,9 +1953,19 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   e->nctx_full = (cfg->frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0);  // batches in flight (+1 being filled)
   if ((rc = materialize_plan(e, e->nctx_full, true))) return bail(rc);
   if ((rc = build_prep_tables(e))) return bail(rc);
-  if (cfg->calibrate_frames > 0 && e->mode == RTP_PREC_MIXED) {   // load-time precision calibration (net.cpp:750-803 is where real weights arrive)
+  // Load-time precision calibration (net.cpp:750-803 is where real weights arrive).  The default split set was chosen on synthetic
+  // weights; weights that come from a FILE are checked by default (one synthetic frame: mixed vs F16X3, and the set is widened if the
+  // check fails) — two of four unseen weight families are 4-7x outside the tolerance with the default set.
+  // calibrate_frames = -1 opts out; > 0 asks for that many frames (also for synthetic weights).
+  int calib = cfg->calibrate_frames;
+  if (calib == 0 && !e->weights_path.empty()) calib = 1;
+  if (calib > 0 && e->mode == RTP_PREC_MIXED) {
     float before = 0.f, after = 0.f;
-    if ((rc = rtp_calibrate_precision(e, nullptr, cfg->calibrate_frames, cfg->calibrate_target, nullptr, 0, &before, &after))) return bail(rc);
+    if ((rc = rtp_calibrate_precision(e, nullptr, calib, cfg->calibrate_target, nullptr, 0, &before, &after))) return bail(rc);
+    if (cfg->calibrate_frames == 0 && (e->split_rules != (cfg->split_layers ? std::string(cfg->split_layers) : std::string(kDefaultSplit)) || e->mode != RTP_PREC_MIXED))
+      fprintf(stderr, "rtpose-mi355x: the default mixed-precision split set measured %.2e of the map maximum on the weights of %s (tolerance 1e-3, target %.1e): "
+                      "now %s \"%s\" at %.2e (rtp_config.calibrate_frames = -1 keeps the default set)\n", before, e->weights_path.c_str(),
+              cfg->calibrate_target > 0 ? cfg->calibrate_target : 0.7e-3f, e->mode == RTP_PREC_MIXED ? "mixed" : "f16x3", e->split_rules.c_str(), after);
   }
   *out = e;
   return RTP_OK;
@@ -1994,6 +2037,7 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
+  if (e->busy_probe && sj == 0 && (rc = busy_mark_stage0(e, cx))) return rc;
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   if (e->B == 1 && !e->use_graph) {  // eager: no staging copy, the conv stack reads the caller's tensor
     cx.slot[0].tag = tag;
@@ -2017,6 +2061,7 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
+  if (e->busy_probe && sj == 0 && (rc = busy_mark_stage0(e, cx))) return rc;
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
   memcpy((char*)cx.host_in + sj * bytes, h_in, bytes);
   if (e->prep_defer) {   // the copy on the copy-only stream; the conv stream learns about it when it has completed (flush_prep / pump)
@@ -2043,6 +2088,7 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint
   if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
+  if (e->busy_probe && sj == 0 && (rc = busy_mark_stage0(e, cx))) return rc;
   if (e->prep_defer && (rc = flush_prep(e, cx, false))) return rc;   // an earlier frame of this batch whose copy is done by now
   cx.slot[sj].has_disp = e->gpu_prep_ok;
   if (e->gpu_prep_ok) {
@@ -2138,6 +2184,14 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   memcpy(&n, sl.host_out, sizeof(int));
   if (tag) *tag = sl.tag;
   stage_ms(e, cx, sl);
+  if (e->busy_probe && e->busy_base && !cx.graph_run && e->busy_spans.size() < 3 * 65536) {
+    float t0 = 0.f, t1 = 0.f;
+    if (sj == 0 && cx.stage0_set && hipEventElapsedTime(&t0, e->busy_base, cx.ev_stage0) == hipSuccess &&
+        hipEventElapsedTime(&t1, e->busy_base, cx.ev[1]) == hipSuccess) { e->busy_spans.push_back(0.f); e->busy_spans.push_back(t0); e->busy_spans.push_back(t1); }
+    if (hipEventElapsedTime(&t0, e->busy_base, sl.ev[0]) == hipSuccess && hipEventElapsedTime(&t1, e->busy_base, sl.ev[4]) == hipSuccess) {
+      e->busy_spans.push_back(1.f); e->busy_spans.push_back(t0); e->busy_spans.push_back(t1);
+    }
+  }
   if (n < 0) {
     if (num_people) *num_people = 0;
     return fail(e, RTP_ERANGE, "connect: a PAF sample coordinate fell outside the net resolution (the reference CHECK-fails here, rtpose.cpp:928)");
@@ -2652,8 +2706,15 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     for (int i = 0; i < e->tev_next; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, e->tev[2 * (size_t)i], e->tev[2 * (size_t)i + 1]) == hipSuccess && ms > 0.f) {
-        e->dom_ms_total += ms; e->dom_launches++;
-        e->dom_ms_pass[e->tev_pass[i] & 3] += ms; e->dom_n_pass[e->tev_pass[i] & 3]++;
+        const int si = e->tev_step[i];
+        if (si >= 0 && si < (int)e->steps.size()) {
+          if (e->step_ms.size() != e->steps.size()) { e->step_ms.assign(e->steps.size(), 0.0); e->step_n.assign(e->steps.size(), 0); }
+          e->step_ms[si] += ms; e->step_n[si]++;
+        }
+        if (si < 0 || si >= (int)e->steps.size() || is_dominant_class(e, e->steps[si])) {
+          e->dom_ms_total += ms; e->dom_launches++;
+          e->dom_ms_pass[e->tev_pass[i] & 3] += ms; e->dom_n_pass[e->tev_pass[i] & 3]++;
+        }
       }
     }
     e->tev_next = 0;
@@ -2671,16 +2732,19 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
   }
   if (enable >= 0) {
     if ((enable != 0) != e->time_dominant && !e->fifo.empty()) return fail(e, RTP_EAGAIN, "kernel timing can only be switched on an idle engine");
-    if ((enable != 0) != e->time_dominant || enable == 2) {  // 2 = on + reset
+    if ((enable != 0) != e->time_dominant || enable >= 2) {  // 2 = on + reset; 3 = on + reset, every step of the plan
       e->dom_ms_total = 0; e->dom_launches = 0;
       for (int i = 0; i < 4; ++i) { e->dom_ms_pass[i] = 0; e->dom_n_pass[i] = 0; }
+      e->step_ms.assign(e->steps.size(), 0.0); e->step_n.assign(e->steps.size(), 0);
     }
     e->time_dominant = enable != 0;
+    e->time_all = enable == 3;
     if (e->time_dominant) {
       if (e->tev.empty()) {
         e->tev.assign((size_t)2 * rtp_engine::TEV_PAIRS, nullptr);
         for (hipEvent_t& ev : e->tev) HIPCHK(e, hipEventCreate(&ev));
         e->tev_pass.assign(rtp_engine::TEV_PAIRS, 1);
+        e->tev_step.assign(rtp_engine::TEV_PAIRS, -1);
       }
       e->tev_next = 0;
     }
@@ -2693,6 +2757,43 @@ int rtp_debug_f32_to_e4m3(const float* in, unsigned char* out, int n) {
   if (!in || !out || n < 0) return RTP_EINVAL;
   for (int i = 0; i < n; ++i) out[i] = f32_to_e4m3(in[i]);
   return RTP_OK;
+}
+
+// Stream-busy account without a profiler.  enable = 1: on + reset (idle engine), 0: off, -1: read only.  spans (may be NULL): up to `cap`
+// triples {kind, start_ms, end_ms} since the probe was switched on — kind 0: a batch on its conv stream, from the staging of its first
+// input (H2D / pre-processing) to the end of its conv stack; kind 1: one frame's post-processing chain incl. the D2H of its joints.
+// Returns the number of triples recorded.  The union of the spans over the wall between the first start and the last end is the share
+// of the time the engine had work on the GPU; 1 - that is time in which NO stream of the engine had anything to run.
+int rtp_busy_probe(rtp_engine* e, int enable, float* spans, int cap) {
+  if (!e) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  if (enable >= 0) {
+    if (!e->fifo.empty()) return fail(e, RTP_EAGAIN, "the busy probe can only be switched on an idle engine");
+    if (enable == 1) {
+      if (!e->busy_base) HIPCHK(e, hipEventCreate(&e->busy_base));
+      e->busy_spans.clear();
+      for (Ctx& cx : e->ctx) cx.stage0_set = false;
+      HIPCHK(e, hipEventRecord(e->busy_base, e->ctx[0].stream));
+      HIPCHK(e, hipEventSynchronize(e->busy_base));
+    }
+    e->busy_probe = enable == 1;
+  }
+  const int n = (int)(e->busy_spans.size() / 3);
+  if (spans) memcpy(spans, e->busy_spans.data(), sizeof(float) * 3 * (size_t)std::min(n, std::max(cap, 0)));
+  return n;
+}
+
+// Per-step totals of a timing pass switched on with rtp_kernel_timing(e, 3, ..): ms[i] / launches[i] for plan step i (the order of
+// rtp_plan_summary's "step" lines); returns the number of steps.  Harvest first with rtp_kernel_timing(e, -1, ..) on an idle engine.
+int rtp_kernel_timing_steps(const rtp_engine* e, double* ms, long* launches, int cap) {
+  if (!e || !ms || !launches || cap < 0) return RTP_EINVAL;
+  const int n = (int)e->steps.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    ms[i] = i < (int)e->step_ms.size() ? e->step_ms[i] : 0.0;
+    launches[i] = i < (int)e->step_n.size() ? e->step_n[i] : 0;
+  }
+  return n;
 }
 
 // Per-pass-count breakdown of rtp_kernel_timing's totals: ms[p], launches[p] for p = 1..3 MFMA passes (index 0 unused).
@@ -2866,9 +2967,18 @@ int rtp_device_local_cpus(int device_id, char* buf, size_t buflen) {
 // error most is promoted; when every group is in and the error still exceeds the target the engine falls back to F16X3.
 int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes, float target, char* rules_out, size_t rules_len,
                             float* err_before, float* err_after) {
-  SYNC_GUARD;
+  // (no process-wide lock across this function: every re-plan and every tap below takes g_sync_mutex for its own captures / synchronous
+  // calls, so other engines of the process — rtpose.bin --num_gpu N --calibrate K — interleave with the trials instead of queueing behind
+  // the dozens of seconds a calibration can take)
   int rc;
   if ((rc = need_idle(e))) return rc;
+  if (e->mode == RTP_PREC_F16X3 && e->calib_fell_back) {   // an earlier calibration ended in the parity-grade mode: nothing is left to adjust
+    if (err_before) *err_before = 0.f;
+    if (err_after) *err_after = 0.f;
+    if (rules_out && rules_len) snprintf(rules_out, rules_len, "@f16x3");
+    e->calib_report += "; called again: already RTP_PREC_F16X3 (every layer runs three fp16 passes), nothing to adjust";
+    return RTP_OK;
+  }
   if (e->mode != RTP_PREC_MIXED) return fail(e, RTP_EINVAL, "rtp_calibrate_precision adjusts the split set of RTP_PREC_MIXED (engine precision is %d)", e->mode);
   if (nframes < 1 || nframes > 64) return fail(e, RTP_EINVAL, "calibration frames %d out of range [1, 64]", nframes);
   if (!(target > 0.f)) target = 0.7e-3f;
@@ -2888,7 +2998,14 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   // put the plan it came with back (best effort) and report the original error
   auto bail = [&](int code) {
     const std::string msg = e->err;
-    (void)replan(e, RTP_PREC_MIXED, base_rules, false);
+    if (replan(e, RTP_PREC_MIXED, base_rules, false) != RTP_OK) {
+      // the restore failed too (e.g. the same out-of-memory condition): the engine has NO plan.  Mark it: every entry point that would
+      // touch a context reports RTP_EHIP instead of dereferencing an empty vector; rtp_engine_destroy still works.
+      drop_plan(e);
+      e->broken = true;
+      e->err = msg + " (and the engine's previous plan could not be restored: the engine is unusable, destroy it)";
+      return code;
+    }
     e->err = msg;
     return code;
   };
@@ -2899,7 +3016,7 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   double norm = 0;
   for (float v : ref) norm = std::max(norm, (double)std::fabs(v));
   if (!(norm > 0) || !std::isfinite(norm)) {
-    (void)replan(e, RTP_PREC_MIXED, base_rules, false);
+    if (bail(RTP_ERANGE) && e->broken) return RTP_ERANGE;
     return fail(e, RTP_ERANGE, "calibration: the reference maps are %s (weights / frames out of range for fp16 storage?)", norm > 0 ? "not finite" : "all zero");
   }
   auto measure = [&](double* err) -> int {
@@ -2989,7 +3106,8 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
     rep << "; err " << err << " > target with every group switched: falling back to RTP_PREC_F16X3";
     err = 0;
   }
-  if ((rc = replan(e, final_mode, rules, false))) return bail(rc);
+  if ((rc = replan(e, final_mode, final_mode == RTP_PREC_MIXED ? rules : base_rules, false))) return bail(rc);
+  e->calib_fell_back = final_mode == RTP_PREC_F16X3;   // (rtp_get_split_layers then reports precision RTP_PREC_F16X3 next to the caller's own rule list: the rules do not apply in that mode)
   if (final_mode == RTP_PREC_MIXED && (rc = measure(&err))) return bail(rc);
   if (err_after) *err_after = (float)err;
   rep << "; final " << (final_mode == RTP_PREC_MIXED ? "mixed" : "f16x3") << " set \"" << rules << "\" err " << err;
@@ -3018,7 +3136,16 @@ uint64_t plan_hash(const rtp_engine* e) {
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
   mix(e->weights_bytes); mix(e->convs.size()); mix((uint64_t)e->mode);
-  for (auto& c : e->convs) { mix(c.w_off); mix(c.b_off); mix(c.w_bytes); mix((uint64_t)c.cfg); mix((uint64_t)c.nchunk); mix((uint64_t)c.h8); for (char ch : c.name) mix((uint64_t)(unsigned char)ch); }
+  mix((uint64_t)e->prec); mix((uint64_t)e->split_fp8);
+  for (auto& c : e->convs) {
+    mix(c.w_off); mix(c.b_off); mix(c.w_bytes); mix((uint64_t)c.cfg); mix((uint64_t)c.nchunk); mix((uint64_t)c.h8);
+    // what decides the CONTENTS of the packed arena at equal sizes: which operand the second pass carries (":w" = W_lo, ":a" = W_hi
+    // again), fp16 instead of fp8 corrections (":x"), the chunking, the kernel the weights are packed for
+    mix((uint64_t)c.split_w); mix((uint64_t)c.split_a); mix((uint64_t)c.no_h8); mix((uint64_t)c.ncp); mix((uint64_t)c.rowb); mix((uint64_t)c.CoutP);
+    mix((uint64_t)c.Cin_p); mix((uint64_t)c.fused); mix((uint64_t)c.fused_chunks); mix((uint64_t)c.direct_first); mix((uint64_t)c.impl); mix((uint64_t)c.k); mix((uint64_t)c.pool);
+    for (char ch : c.name) mix((uint64_t)(unsigned char)ch);
+  }
+  for (char ch : e->split_rules) mix((uint64_t)(unsigned char)ch);
   return h;
 }
 size_t ref_floats(const rtp_engine* e) {

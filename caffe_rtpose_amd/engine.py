@@ -499,6 +499,13 @@ class Engine:
         self._chk(lib.rtp_device_synchronize(self.h))
 
     # ---- one-time weight distribution between replicas
+    def weight_blob_bytes(self):
+        """Length of this plan's weight blob without exporting one (no D2H copy of the arena)."""
+        n = lib.rtp_weight_blob_bytes(self.h)
+        if n < 0:
+            raise RtpError(n, "rtp_weight_blob_bytes")
+        return int(n)
+
     def weight_blob(self):
         n = lib.rtp_weight_blob_bytes(self.h)
         buf = np.empty(n, np.uint8)
@@ -529,6 +536,26 @@ class Engine:
         n = (C.c_long * 4)()
         self._chk(lib.rtp_kernel_timing_by_passes(self.h, ms, n))
         return {p: (ms[p], n[p]) for p in (1, 2, 3) if n[p]}
+
+    def kernel_timing_steps(self):
+        """[(ms, launches)] per plan step of a timing pass switched on with kernel_timing(3) (harvest with kernel_timing(-1) first)."""
+        cap = 512
+        ms = (C.c_double * cap)()
+        n = (C.c_long * cap)()
+        k = lib.rtp_kernel_timing_steps(self.h, ms, n, cap)
+        if k < 0:
+            raise RtpError(k, "rtp_kernel_timing_steps")
+        return [(ms[i], n[i]) for i in range(min(k, cap))]
+
+    def busy_probe(self, enable=-1):
+        """rtp_busy_probe: returns the spans recorded so far as an [n][3] float32 array {kind, start_ms, end_ms}."""
+        n = lib.rtp_busy_probe(self.h, enable, None, 0)
+        if n < 0:
+            raise RtpError(n, lib.rtp_last_error(self.h).decode())
+        out = np.zeros((n, 3), np.float32)
+        if n:
+            lib.rtp_busy_probe(self.h, -1, _f(out), n)
+        return out
 
     def bench_dominant_conv(self, iters=50):
         ms = C.c_float()

@@ -103,7 +103,11 @@ typedef struct rtp_config {
   int calibrate_frames;    /* > 0 (RTP_PREC_MIXED only): rtp_engine_create ends with                         *
                             * rtp_calibrate_precision(e, NULL, calibrate_frames, calibrate_target, ...) on    *
                             * synthetic frames, i.e. the split set is checked — and widened if necessary —    *
-                            * on the weights that were just loaded (net.cpp:750-803).  0 = off.               */
+                            * on the weights that were just loaded (net.cpp:750-803).                          *
+                            * 0 (default): that check runs with ONE frame when weights_path != NULL (weights   *
+                            * from a file: the default set was chosen on synthetic ones; ~2-3 s, a line on     *
+                            * stderr if the set had to change) and not at all for synthetic weights.           *
+                            * -1: never (the split set stays exactly rtp_config.split_layers / the default).   */
   float calibrate_target;  /* max |mixed - f16x3| / max |map| the calibration accepts (<= 0: 0.7e-3)         */
 } rtp_config;
 
@@ -328,6 +332,17 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
 /* The same totals split by the MFMA pass-times of the launch: 1 = plain fp16 layer, 2 = fp16 + one fp8 error-compensation
  * chunk per channel group (RTP_PREC_MIXED on 3x3 / 7x7 layers), 3 = three fp16 passes (RTP_PREC_F16X3); index 0 is unused. */
 int rtp_kernel_timing_by_passes(const rtp_engine* e, double ms[4], long launches[4]);
+/* enable = 3 in rtp_kernel_timing: on AND reset with an event pair around EVERY step of the plan (all convolution launches, the
+ * branch-tail launches, conv1_1), not only the dominant class — its totals keep their meaning.  rtp_kernel_timing_steps then returns,
+ * per plan step i (the order of rtp_plan_summary's "step" lines), the summed milliseconds and the number of launches timed; return
+ * value = number of steps (fill at most `cap`).  bench.py groups them into kernel classes (`roofline.classes`). */
+int rtp_kernel_timing_steps(const rtp_engine* e, double* ms, long* launches, int cap);
+/* An UNPROFILED account of when the engine had work on the GPU (rocprofv3's timeline carries the tracer's own overhead).  enable = 1:
+ * on + reset (idle engine only), 0: off, -1: read.  While on, rtp_collect reads — from events the per-frame path records anyway —
+ * {kind, start_ms, end_ms} triples since the switch-on: kind 0 = one batch on its conv stream, from the staging of its first input to
+ * the end of its conv stack; kind 1 = one frame's post-processing chain incl. the D2H of its joints.  Returns the number of triples
+ * (at most `cap` are copied to `spans`, which may be NULL). */
+int rtp_busy_probe(rtp_engine* e, int enable, float* spans, int cap);
 /* Host float -> OCP e4m3 (round to nearest even, clamped to +-448): how the fp8 weight copies of split layers are made. */
 int rtp_debug_f32_to_e4m3(const float* in, unsigned char* out, int n);
 

@@ -256,6 +256,11 @@ def explain(model, res_r, res_e, max_peaks, net_w, net_h, disp_w, disp_h, thr, s
             attr["limb"] += 1         # its peak takes part in a flipped PAF test / an order inversion of one of its limbs
         else:
             attr["propagated"] += 1   # downstream: a greedy pick or a person row re-routed by flips elsewhere
+    # ---- counterfactual replay: the per-joint proof (tests/_replay.py) --------------------------------------------------------------
+    import _replay
+    rep = _replay.replay(model, res_r, res_e, kr, ke, mr, pk_r, pk_e, tr, te, max_peaks, net_w, net_h, disp_w, disp_h, thr, e_heat, e_paf, pmax,
+                         tol_px / max(disp_w / net_w, disp_h / net_h))
+    out.update(rep)
     flips = []
     for part, xe, ye, xr, yr, _dc in out_of_tol:
         k_e, k_r = peak_key("engine", part, xe, ye), peak_key("ref", part, xr, yr)
@@ -264,7 +269,10 @@ def explain(model, res_r, res_e, max_peaks, net_w, net_h, disp_w, disp_h, thr, s
     out["out_of_tol_is_flip"] = flips
     n_struct = len(structural) + sum(flips)
     n_roots = sum(roots.values())
-    ok = not unexplained and (n_struct == 0 or n_roots > 0)
+    # every structural joint is explained iff (a) every root flip found above is a near-tie, and (b) the reference side replayed with the
+    # engine's outcome forced at every decision that differs for the same inputs — each of them a checked near-tie — gives the ENGINE's
+    # people exactly (no inference about what is "downstream": it is computed)
+    ok = not unexplained and (n_struct == 0 or n_roots > 0) and rep["replay_identical"] and rep["replay_unexplained"] == 0
     out.update(root_flips=roots, root_flips_total=n_roots, unexplained=len(unexplained), unexplained_detail=[f"{k}: margin {m:.3e} >= allowance {a:.3e}: {w}" for k, m, a, w in unexplained[:8]],
                worst_margin_over_allowance=worst, joints_structural=n_struct, structural_explained=n_struct if ok else 0, attribution=attr,
                score_bound_max=bound_max)
@@ -280,4 +288,9 @@ def merge(reports):
     for k in ("e_map", "e_pos_net_px", "worst_margin_over_allowance"):
         tot[k] = float(max([r[k] for r in reports], default=0.0))
     tot["unexplained_detail"] = [d for r in reports for d in r["unexplained_detail"]][:8]
+    tot["replay_identical"] = bool(all(r["replay_identical"] for r in reports))
+    tot["replay_unexplained"] = int(sum(r["replay_unexplained"] for r in reports))
+    tot["replay_unexplained_detail"] = [d for r in reports for d in r["replay_unexplained_detail"]][:8]
+    tot["replay_forced"] = {k: int(sum(r["replay_forced"][k] for r in reports)) for k in (reports[0]["replay_forced"] if reports else {})}
+    tot["replay_worst_margin_over_allowance"] = float(max([r["replay_worst_margin_over_allowance"] for r in reports], default=0.0))
     return tot

@@ -1,0 +1,58 @@
+"""bench.py's host-side bookkeeping that needs no GPU: the per-kernel-class rows of `roofline.classes` (from per-step event timings and
+rtp_plan_summary's step lines) and the union-of-spans account behind `gpu_busy`."""
+import importlib.util
+import os
+
+import numpy as np
+
+import _oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("rtp_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_classes_cover_every_step_and_sum_to_the_models_flops():
+    import caffe_rtpose_amd as r
+    b = _bench()
+    cfg = r.Config(net_w=656, net_h=368, precision=r.PREC_MIXED, frames_in_flight=7, batch_frames=2)
+    plan = [ln for ln in r.plan_summary(cfg).splitlines() if ln.startswith("step ")]
+    layers = orc.Net(0).convs
+    times = [(0.050 * 40, 40)] * len(plan)            # 50 us per launch, 40 launches each
+    classes, total = b.kernel_classes(plan, layers, times, 656, 368, 2, 2.5e15)
+    assert abs(total - 0.050 * len(plan)) < 1e-9
+    assert sum(c["steps_per_batch"] for c in classes.values()) == len(plan)
+    assert classes["dominant 7x7 128->128 pair plain"]["steps_per_batch"] == 8 and classes["dominant 7x7 128->128 pair 2q"]["steps_per_batch"] == 12
+    assert classes["stage-entry 7x7 185->128 pair plain"]["steps_per_batch"] == 2 and classes["stage-entry 7x7 185->128 pair 2q"]["steps_per_batch"] == 3
+    assert classes["branch tails 1x1->1x1 (conv_pw2)"]["steps_per_batch"] == 6 and classes["conv1_1 (conv_first)"]["steps_per_batch"] == 1
+    # algorithmic FLOPs: every class's TFLOP/s x its time adds up to the model's 484.634 GFLOP per image x 2 images
+    flops = sum(c["tflops"] * 1e12 * c["ms_per_batch"] * 1e-3 for c in classes.values())
+    assert abs(flops / (2 * 484.634e9) - 1) < 1e-4
+    dom = classes["dominant 7x7 128->128 pair plain"]
+    assert abs(dom["tflops"] - 24.225775616e9 / 50e-6 / 1e12) < 0.5 and abs(sum(c["share_of_batch"] for c in classes.values()) - 1) < 1e-9
+    # MPI at batches of 5: the stage-entry shape is 172 -> 128
+    cfg = r.Config(model=r.MODEL_MPI_15, net_w=496, net_h=368, precision=r.PREC_MIXED, frames_in_flight=10, batch_frames=5)
+    plan = [ln for ln in r.plan_summary(cfg).splitlines() if ln.startswith("step ")]
+    classes, _ = b.kernel_classes(plan, orc.Net(1).convs, [(1.0, 10)] * len(plan), 496, 368, 5, 2.5e15)
+    flops = sum(c["tflops"] * 1e12 * c["ms_per_batch"] * 1e-3 for c in classes.values())
+    assert abs(flops / (5 * 361.695e9) - 1) < 1e-4 and any(k.startswith("stage-entry 7x7 172->128") for k in classes)
+
+
+def test_busy_account_is_the_union_of_the_spans():
+    b = _bench()
+    spans = []
+    for i in range(100):      # conv spans back to back with a 0.2 ms gap every 1 ms; post chains inside the next span
+        spans.append((0, i * 1.0, i * 1.0 + 0.8))
+        spans.append((1, i * 1.0 + 0.85, i * 1.0 + 0.95))
+    acc = b.busy_account(np.array(spans, np.float32))
+    assert abs(acc["busy_frac"] - 0.9) < 0.01 and abs(acc["idle_frac"] - 0.1) < 0.01
+    assert abs(acc["conv_streams_busy_frac"] - 0.8) < 0.01 and abs(acc["post_chains_busy_frac"] - 0.1) < 0.01
+    two = np.array([(0, i * 0.5, i * 0.5 + 0.9) for i in range(100)], np.float32)   # two stacks at a time
+    acc = b.busy_account(two)
+    assert acc["busy_frac"] > 0.999 and 1.7 < acc["conv_stacks_concurrent_avg"] < 1.9
+    assert b.busy_account(np.zeros((3, 3), np.float32)) is None

@@ -114,3 +114,42 @@ def test_calibration_at_engine_creation_and_argument_checks():
     with pytest.raises(r.RtpError):         # there is no split set to adjust outside RTP_PREC_MIXED
         e16.calibrate_precision(nframes=1)
     e16.close()
+
+
+@pytest.mark.parametrize("family", ["lognormal_channels", "decaying_spectrum"])
+def test_weights_from_a_file_are_checked_by_default(family, tmp_path):
+    """calibration helps only if someone calls it — so with `weights_path != NULL` the engine calls it itself.  Two weight
+    families that are 4-7x OUTSIDE +-1e-3 with the default split set, written to a .caffemodel and loaded through an UNTOUCHED default
+    configuration (net.cpp:750-803 CopyTrainedLayersFrom is where trained weights arrive): inside the tolerance against the fp32 CPU oracle,
+    the set reported by rtp_get_split_layers / the calibration report / one line on stderr; calibrate_frames = -1 keeps the default set
+    (and stays outside the tolerance: the opt-out is real)."""
+    import caffe_rtpose_amd as r
+    proto, model = tmp_path / "net.prototxt", tmp_path / "w.caffemodel"
+    e0 = r.Engine(r.Config(net_w=W, net_h=H, precision=r.PREC_MIXED, frames_in_flight=2, batch_frames=1))
+    wts, _ = _families.make(e0.conv_layers(), family, 7, _synth.random_frame(1, H, W, seed=41))
+    for i, (name, *_r) in enumerate(e0.conv_layers()):
+        e0.set_conv_weights(i, *wts[name])
+    default_rules = e0.split_layers()[0]
+    e0.save_caffemodel(model)
+    e0.save_prototxt(proto)
+    x = _synth.random_frame(1, H, W, seed=42)
+    ref = _oracle_maps(e0, x)
+    e0.close()
+    t0 = time.perf_counter()
+    e = r.Engine(r.Config(proto_path=str(proto), weights_path=str(model), net_w=W, net_h=H))    # nothing else set: rtp_config_default
+    dt = time.perf_counter() - t0
+    rules, mode = e.split_layers()
+    err = _err(e, x, ref)
+    print(f"\n[default calibration {family}] engine creation {dt:.1f} s; set \"{rules}\" mode {mode}; {err:.3e} of the map maximum vs the fp32 oracle\n   ", e.calibration_report())
+    assert e.calibration_report().startswith("target 0.0007; frames 1;") and "final" in e.calibration_report()
+    assert mode == r.PREC_F16X3 or (rules != default_rules and rules.startswith(default_rules))
+    assert err <= 1e-3
+    e.submit(x, tag=1)
+    assert e.collect()[0] == 1
+    e.close()
+    e = r.Engine(r.Config(proto_path=str(proto), weights_path=str(model), net_w=W, net_h=H, calibrate_frames=-1))
+    assert e.calibration_report() == "" and e.split_layers() == (default_rules, r.PREC_MIXED)
+    assert _err(e, x, ref) > 1e-3
+    e.close()
+    with pytest.raises(r.RtpError):
+        r.Engine(r.Config(net_w=W, net_h=H, calibrate_frames=-2))

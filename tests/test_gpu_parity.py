@@ -404,7 +404,7 @@ def test_weights_roundtrip_caffemodel_and_prototxt(tmp_path):
     e.save_prototxt(tmp_path / "net.prototxt")
     e.close()
     e2 = _engine(net_w=W, net_h=H, frames_in_flight=1, proto_path=str(tmp_path / "net.prototxt"),
-                 weights_path=str(tmp_path / "w.caffemodel"))
+                 weights_path=str(tmp_path / "w.caffemodel"), calibrate_frames=-1)   # (-1: weights from a file are checked by default and the split set may change)
     b = e2.forward_heatmaps(x)
     assert np.array_equal(a, b)
     e2.close()
@@ -832,7 +832,23 @@ def test_weight_blob_and_peer_copy_reproduce_the_source_engine():
         other.load_weight_blob(blob)    # another plan (precision): refused, nothing written
     with pytest.raises(r.RtpError):
         other.copy_weights_from(src)
-    for e in (src, a, b, other):
+    # same sizes, other CONTENTS: a layer split ":w" carries W_lo in its second pass, split ":a" carries W_hi again — equal nchunk and
+    # byte counts, another arena.  The plan hash must tell them apart, and likewise ":x" (fp16 instead of fp8 corrections).
+    kw3 = dict(net_w=160, net_h=96, precision=r.PREC_MIXED, frames_in_flight=1, batch_frames=1)
+    ew = _engine(split_layers="conv2_:w,@1x1", **kw3)
+    ea = _engine(split_layers="conv2_:a,@1x1", **kw3)
+    ew2 = _engine(split_layers="conv2_:w,@1x1", synthetic_seed=3, **kw3)
+    blob_w = ew.weight_blob()
+    assert len(blob_w) == ea.weight_blob_bytes()                # the sizes agree, so only the hash can refuse it
+    before = ea.forward_heatmaps(x)
+    with pytest.raises(r.RtpError):
+        ea.load_weight_blob(blob_w)
+    with pytest.raises(r.RtpError):
+        ea.copy_weights_from(ew)
+    assert np.array_equal(ea.forward_heatmaps(x), before)       # refused = nothing written
+    ew2.load_weight_blob(blob_w)                                # the same split set takes it
+    assert np.array_equal(ew2.forward_heatmaps(x), ew.forward_heatmaps(x))
+    for e in (src, a, b, other, ew, ea, ew2):
         e.close()
 
 

@@ -154,6 +154,12 @@ def test_every_flip_of_a_sub_tolerance_perturbation_is_explained(model, seed, wh
     assert ex["unexplained"] == 0, ex["unexplained_detail"]
     assert ex["root_flips"]["nms"] > 0 and ex["worst_margin_over_allowance"] < 0.6   # (a margin at 60 % of its allowance would mean the bound has no slack left)
     assert ex["structural_explained"] == rep["joints_structural"] == ex["joints_structural"]
+    # the per-joint proof (tests/_replay.py): the reference side replayed with the engine's outcome forced at every decision that differs for
+    # the same inputs — each of them a checked near-tie — gives the engine's people exactly; nothing is "assumed downstream"
+    print("replay:", ex["replay_forced"], ex["replay_worst_margin_over_allowance"], ex["replay_unexplained_detail"])
+    assert ex["replay_identical"] and ex["replay_unexplained"] == 0 and ex["replay_people"] == ne
+    assert ex["replay_forced"]["nms"] == ex["root_flips"]["nms"] and ex["replay_forced_total"] >= ex["replay_forced"]["nms"]
+    assert ex["replay_worst_margin_over_allowance"] < 0.8
     assert _parity.verdict(_parity.merge([rep]), map_err=7e-4, explained=ex["structural_explained"]).startswith(("pass", "numeric pass"))
 
 
@@ -176,6 +182,8 @@ def test_a_difference_that_is_not_a_near_tie_is_not_explained():
     # the deviation this "bug" causes is huge, so margins alone would pass under 2 e_map — but the peak scores moved out of the confidence tolerance
     assert ex["unexplained"] > 0 and any(d_.startswith(("peak-score", "map-deviation", "nms")) for d_ in ex["unexplained_detail"])
     assert ex["structural_explained"] == 0
+    # (the replay's allowances are multiples of the same measured deviation — huge here — so ITS near-tie tests pass; what fails the verdict is
+    # the deviation guard above: a replay can only be trusted inside the tolerance, and explain() demands both)
     # (b) uniform deviation of 5e-3: outside +-1e-3
     res_e2, _, ne2, je2 = _chain(model, (base * np.float32(1.005)).astype(np.float32), thr)
     rep2 = _parity.people_parity(je2[:ne2], jr[:nr])
@@ -185,6 +193,7 @@ def test_a_difference_that_is_not_a_near_tie_is_not_explained():
     # (c) people differ (a person dropped after the fact) while no decision differs: nothing explains it
     ex3 = _explain.explain(model, res_r, res_r, maxp, W, H, 1280, 720, thr, [("ref", 0, 1, float(jr[0, 1, 0]), float(jr[0, 1, 1]), float(jr[0, 1, 2]))])
     assert ex3["root_flips_total"] == 0 and ex3["unexplained"] == 0 and ex3["joints_structural"] == 1 and ex3["structural_explained"] == 0
+    assert ex3["replay_identical"] and ex3["replay_forced_total"] == 0   # (identical maps replay identically: the claimed difference has no cause in the chain)
 
 
 class _FakeEngine:

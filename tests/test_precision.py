@@ -185,6 +185,9 @@ def test_people_level_parity_of_the_benched_mode(cfg):
     assert rep["map_max_err"] <= 1e-3 and rep["post_on_engine_maps_bit_exact"]
     assert rep["explain"]["unexplained"] == 0, rep["explain"]["unexplained_detail"]
     assert rep["structural_explained"] == rep["joints_structural"]
+    # per-joint proof: the reference chain replayed with ONLY the near-tie decisions forced to the engine's outcome yields the engine's people
+    assert rep["replay_identical"] and rep["explain"]["replay_unexplained"] == 0, rep["explain"]["replay_unexplained_detail"]
+    assert rep["explain"]["replay_worst_margin_over_allowance"] < 0.8
     assert rep["joints_structural"] == 0 or sum(rep["explain"]["root_flips"].values()) > 0
     assert rep["explain"]["worst_margin_over_allowance"] < 0.8    # the flips are near-ties with room to spare, not decisions at the edge of the allowance
     # The random-weight network's maps are noise: hundreds of maxima, some of them near-ties.  Each flip re-numbers the raster-ordered
