@@ -147,7 +147,7 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN, bool ILV = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
                                               int kg, int wrem, int wm0, int wn0, int lane, int img, int m0, int n0) {
-  static_assert(KSPLIT * BM * BN * 4 <= 64 * 1024, "partials fit in 64 KiB of LDS");
+  static_assert(KSPLIT * BM * BN * 4 <= 160 * 1024, "partials fit in LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = (float*)smem;
 #pragma unroll
@@ -218,7 +218,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
                                                    int kg, int wm0, int wn0, int lane, int img, int pair, int x0, int n0) {
-  static_assert(KSPLIT * BM * BN * 4 <= 64 * 1024, "partials fit in 64 KiB of LDS");
+  static_assert(KSPLIT * BM * BN * 4 <= 160 * 1024, "partials fit in LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = (float*)smem;
 #pragma unroll

@@ -39,6 +39,7 @@ void rtp_internal_cubic_tab2d(short* tab);
 double rtp_internal_warp_inverse_scale(double s);
 bool rtp_internal_area_fast(int sw, int sh, int dw, int dh, int* ix, int* iy);
 int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::vector<int>* si, std::vector<float>* alpha);
+void rtp_internal_linear_area_table(int ssize, int dsize, std::vector<int>* tab);
 extern "C" double rtp_display_fit_scale(int ow, int oh, int disp_w, int disp_h);
 extern "C" int rtp_preprocess_frame(const unsigned char* bgr, int w, int h, int disp_w, int disp_h, int net_w, int net_h, int num_scales,
                                     double start_scale, double scale_gap, float* net_input, unsigned char* display_bgr, float* frame_scale);
@@ -148,6 +149,7 @@ struct Slot {
 // One batch in flight: the conv stack runs once over filled*num_scales images
 struct Ctx {
   hipStream_t stream = nullptr, spare_stream = nullptr;
+  std::vector<hipStream_t> pad_streams;   // never used: they only take hardware-queue slots in the runtime's round-robin (alloc_ctx)
   unsigned char* arena = nullptr;
   float* input = nullptr;     // device NCHW fp32, batch_frames * num_scales images
   float* host_in = nullptr;   // pinned staging
@@ -583,7 +585,10 @@ int build_plan(rtp_engine* e) {
     if (A.rowb == 64) cands = {CFG_128x64};
     else if (maxcout <= 32 && ring_ok && row_bytes_all % 256 == 0) cands = {CFG_128x32, CFG_128x64, CFG_64x64};
     else if (maxcout <= 64) cands = {CFG_128x64, CFG_64x64};
-    else if (ring_ok && row_bytes_all % 256 == 0) cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64, CFG_128x32};
+    else if (ring_ok && row_bytes_all % 256 == 0) {
+      cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64, CFG_128x32};
+      if (e->prec == 0 && A.k_eff == 7 && maxcout >= 64) cands.push_back(CFG_256x64);   // (chosen by the model where 128-pixel tiles would need two rounds: batches of >= 4 images)
+    }
     else if (ring_ok) cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64};
     else cands = {CFG_128x128, CFG_64x128, CFG_64x64};
     int best = cands.back();
@@ -631,6 +636,10 @@ int build_plan(rtp_engine* e) {
       const bool dominant = A.k_eff == 7 && A.cin == 128;
       if (mode > 0 && has128 && best != CFG_128x128 && wg_best > 128 && wg_best <= 256 && wg_128 >= 100 && wg_128 <= 128 && (mode >= 2 || !dominant))
         best = CFG_128x128;
+    }
+    {
+      static const char* d256 = RTP_EXP_ENV("RTP_DOM_256");   // experiments: 1 = 256x64 tiles for the 7x7 layers whatever the batch (half-chip launches of double-size workgroups at batch_frames 2); 2 = the dominant shape only
+      if (d256 && ring_ok && A.k_eff == 7 && std::find(cands.begin(), cands.end(), (int)CFG_256x64) != cands.end() && (d256[0] == '1' || (d256[0] == '2' && A.cin == 128))) best = CFG_256x64;
     }
     if (const char* ov = RTP_EXP_ENV("RTP_TILE_OVERRIDE")) {  // experiments: "conv2_1=3,conv3_1=3" forces tile ids (kernels.h ConvCfg) per layer
       const std::string key = A.name + "=";
@@ -1470,6 +1479,20 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
     if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0 && !(own0 && own0[0] == '1')))) return rc;
   }
   {
+    // HIP deals its hardware queues to streams round-robin in creation order (4 queues).  A context owns batch_frames streams (its conv
+    // stream, which also carries frame 0's chain, + one per further frame): with batch_frames = 4 (8, ..) EVERY context's conv stream would
+    // land on the same hardware queue and the conv stacks of different batches would run strictly one after the other — measured
+    // (profiles/r05_experiments.txt): batches of 4 pipelined no faster than one batch at a time.  Two unused streams per context restore the
+    // arrangement batches of 2 have by construction: conv stacks alternate between two queues.
+    static const char* pad_env = RTP_EXP_ENV("RTP_STREAM_PAD");
+    const int pad = pad_env ? atoi(pad_env) : ((e->B % 4) == 0 && !planned ? 2 : 0);
+    for (int i = 0; i < pad; ++i) {
+      hipStream_t d = nullptr;
+      HIPCHK(e, hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
+      cx.pad_streams.push_back(d);
+    }
+  }
+  {
     static const char* sh1 = RTP_EXP_ENV("RTP_POST_SHARE1");  // experiments: 1 = frame 0's chain runs on frame 1's stream (behind nothing of the conv queues)
     if (sh1 && sh1[0] == '1' && e->B >= 2 && !planned && cx.slot[0].stream == cx.stream) cx.slot[0].stream = cx.slot[1].stream;
   }
@@ -1501,6 +1524,7 @@ void free_ctx(Ctx& cx) {
   if (cx.ev_stage0) { (void)hipEventDestroy(cx.ev_stage0); cx.ev_stage0 = nullptr; }
   if (cx.stream) (void)hipStreamDestroy(cx.stream);
   if (cx.spare_stream) (void)hipStreamDestroy(cx.spare_stream);
+  for (hipStream_t d : cx.pad_streams) if (d) (void)hipStreamDestroy(d);
   cx = Ctx();
 }
 
@@ -1526,7 +1550,7 @@ int invalidate_graphs(rtp_engine* e) {
 int build_prep_tables(rtp_engine* e) {
   SYNC_GUARD;
   e->gpu_prep_ok = false;
-  struct Host { int tw, th, identity, fx = 0, fy = 0; std::vector<int> xs, xsi, ys, ysi; std::vector<float> xa, ya; };
+  struct Host { int tw, th, identity, fx = 0, fy = 0, linear = 0; std::vector<int> xs, xsi, ys, ysi, lx, ly; std::vector<float> xa, ya; };
   std::vector<Host> hs(e->N);
   size_t bytes = 0;
   for (int i = 0; i < e->N; ++i) {
@@ -1535,15 +1559,18 @@ int build_prep_tables(rtp_engine* e) {
     h.tw = (int)(16 * std::ceil(e->cfg.net_w * scale / 16));
     h.th = (int)(16 * std::ceil(e->cfg.net_h * scale / 16));
     h.identity = (h.tw == e->cfg.disp_w && h.th == e->cfg.disp_h) ? 1 : 0;
-    if (h.tw > e->cfg.disp_w || h.th > e->cfg.disp_h) return RTP_OK;  // enlarging level: host path only
-    if (!h.identity && rtp_internal_area_fast(e->cfg.disp_w, e->cfg.disp_h, h.tw, h.th, &h.fx, &h.fy)) {
+    if (h.tw > e->cfg.disp_w || h.th > e->cfg.disp_h) {   // an axis is enlarged (--resolution smaller than the level): cv::resize's bilinear kernel with area-mode coefficients
+      h.linear = 1;
+      rtp_internal_linear_area_table(e->cfg.disp_w, h.tw, &h.lx);
+      rtp_internal_linear_area_table(e->cfg.disp_h, h.th, &h.ly);
+    } else if (!h.identity && rtp_internal_area_fast(e->cfg.disp_w, e->cfg.disp_h, h.tw, h.th, &h.fx, &h.fy)) {
       // integer scale on both axes: block sums, no tables
     } else if (!h.identity) {
       h.fx = h.fy = 0;
       if (rtp_internal_area_table(e->cfg.disp_w, h.tw, &h.xs, &h.xsi, &h.xa)) return RTP_OK;
       if (rtp_internal_area_table(e->cfg.disp_h, h.th, &h.ys, &h.ysi, &h.ya)) return RTP_OK;
     }
-    bytes += 256 * 6 + (h.xs.size() + h.xsi.size() + h.ys.size() + h.ysi.size()) * sizeof(int) + (h.xa.size() + h.ya.size()) * sizeof(float);
+    bytes += 256 * 8 + (h.xs.size() + h.xsi.size() + h.ys.size() + h.ysi.size() + h.lx.size() + h.ly.size()) * sizeof(int) + (h.xa.size() + h.ya.size()) * sizeof(float);
   }
   bytes += 32 * 32 * 16 * sizeof(short) + 256;
   std::vector<unsigned char> blob(bytes + 256, 0);
@@ -1563,6 +1590,9 @@ int build_prep_tables(rtp_engine* e) {
     a.ystart = (const int*)(e->prep_tables + put(h.ys.data(), h.ys.size() * sizeof(int)));
     a.ysi = (const int*)(e->prep_tables + put(h.ysi.data(), h.ysi.size() * sizeof(int)));
     a.yalpha = (const float*)(e->prep_tables + put(h.ya.data(), h.ya.size() * sizeof(float)));
+    a.linear = h.linear;
+    a.lx = (const int*)(e->prep_tables + put(h.lx.data(), h.lx.size() * sizeof(int)));
+    a.ly = (const int*)(e->prep_tables + put(h.ly.data(), h.ly.size() * sizeof(int)));
   }
   {
     std::vector<short> t2(32 * 32 * 16);

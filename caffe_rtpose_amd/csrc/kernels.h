@@ -86,7 +86,7 @@ struct ConvParams {
 };
 
 // which tile configuration a conv launch uses
-enum ConvCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_128x64 = 3, CFG_128x32 = 4, CFG_COUNT = 5 };
+enum ConvCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_128x64 = 3, CFG_128x32 = 4, CFG_256x64 = 5, CFG_COUNT = 6 };
 
 struct ConvCfgInfo { int BM, BN; };
 inline ConvCfgInfo conv_cfg_info(int cfg) {
@@ -95,6 +95,7 @@ inline ConvCfgInfo conv_cfg_info(int cfg) {
     case CFG_64x128: return {64, 128};
     case CFG_64x64: return {64, 64};
     case CFG_128x32: return {128, 32};
+    case CFG_256x64: return {256, 64};   // 7x7 layers at batches of >= 4 images: twice the pixels per workgroup (one fill + epilogue per 98 K steps)
     default: return {128, 64};
   }
 }
@@ -162,6 +163,10 @@ struct AreaScale {                    // cv::resize(INTER_AREA) tables of one py
   int fast_x, fast_y;                 // > 0: integer scale on both axes (resizeAreaFast_): block sums instead of the tables
   const int* xstart; const int* xsi; const float* xalpha;   // entries of dst column x: [xstart[x], xstart[x+1])
   const int* ystart; const int* ysi; const float* yalpha;
+  // linear != 0: an axis of this level is ENLARGED — cv::resize(INTER_AREA) then runs its bilinear kernel with area-mode coefficients
+  // (preprocess.cpp linear_area_tab): lx [tw][4] / ly [th][4] = {source index, its clipped neighbour, 11-bit weight, 11-bit weight}
+  int linear;
+  const int* lx; const int* ly;
 };
 hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
                        hipStream_t stream);

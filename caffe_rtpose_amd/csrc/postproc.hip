@@ -731,9 +731,13 @@ static hipError_t ensure_lds(size_t bytes) {
   return e;
 }
 
+// Dynamic-LDS budget of the post-processing kernels: the CU's 160 KiB minus what the kernels declare statically (wave counters, the
+// per-scale geometry, YTab, the sort replica's explicit stack: < 2 KiB in every kernel of this file; 4 KiB reserved).
+constexpr size_t kPostDynLdsMax = 160 * 1024 - 4096;
+
 hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream) {
   const size_t lds1 = (size_t)(p.strip_rows + 2 + NMSF_TROWS) * p.W * sizeof(float) + (size_t)p.W * sizeof(XTab);
-  if (lds1 > 150 * 1024) return hipErrorInvalidValue;
+  if (lds1 > kPostDynLdsMax) return hipErrorInvalidValue;
   if (lds1 > 64 * 1024) {
     hipError_t e = ensure_lds<nms_fused_strip_kernel>(lds1);
     if (e != hipSuccess) return e;
@@ -1316,9 +1320,10 @@ static hipError_t launch_connect_impl(const ConnectParams& p, const ResizeParams
   {
     const size_t extra = 8 + ((size_t)p.num_parts * 3 * (p.max_peaks + 1) + (size_t)p.num_limbs * p.max_peaks * 3 + p.num_limbs) * 4;
     static const char* np = RTP_EXP_ENV("RTP_ASSEMBLE_PRELOAD");  // experiments: 0 = no LDS copy of the assembly inputs
-    pa.assemble_preload = (lds2 + extra <= 150 * 1024 && !(np && np[0] == '0')) ? 1 : 0;
+    pa.assemble_preload = (lds2 + extra <= kPostDynLdsMax && !(np && np[0] == '0')) ? 1 : 0;
     if (pa.assemble_preload) lds2 += extra;
   }
+  if (lds1 > kPostDynLdsMax || lds2 > kPostDynLdsMax) return hipErrorInvalidValue;   // (static LDS of the kernels is inside the reserve)
   if (lds1 > 64 * 1024) {
     e = ensure_lds<connect_match_kernel>(lds1);
     if (e != hipSuccess) return e;

@@ -4,7 +4,8 @@
 //   warp_cubic_kernel : display-fit scale, 1/32-pixel fixed-point coordinates, OpenCV's 2-D table of 15-bit cubic weights,
 //                       one rounding per pixel, BORDER_CONSTANT 0 — pure integer arithmetic.
 //   area_pad_kernel   : per scale, fractional-area resize (float accumulation in the host's order:
-//                       x-sum per source row, then beta-weighted row sum), round-to-nearest-even,
+//                       x-sum per source row, then beta-weighted row sum), round-to-nearest-even — or, where the level ENLARGES
+//                       an axis, OpenCV's fixed-point bilinear kernel with area-mode coefficients —,
 //                       u8/256 - 0.5, centre zero-pad into the net frame (process_and_pad_image).
 // Compiled with -ffp-contract=off.  HBM-bound streaming kernels: 2.8 MB in, 11.6 MB out per 720p frame.
 #include <cstring>
@@ -68,6 +69,18 @@ __global__ __launch_bounds__(256) void area_pad_kernel(const unsigned char* __re
   if (sc.identity) {
     const unsigned char* p = disp + ((size_t)oy * dw + ox) * 3;
     r3[0] = p[0]; r3[1] = p[1]; r3[2] = p[2];
+  } else if (sc.linear) {  // an enlarged axis: HResizeLinear into int rows, VResizeLinear's u8 specialisation (integer arithmetic throughout)
+    const int* tx = sc.lx + ox * 4;
+    const int* ty = sc.ly + oy * 4;
+    const unsigned char* r0 = disp + (size_t)ty[0] * dw * 3;
+    const unsigned char* r1 = disp + (size_t)ty[1] * dw * 3;
+    const int x0 = tx[0] * 3, x1 = tx[1] * 3, a0 = tx[2], a1 = tx[3], b0 = ty[2], b1 = ty[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int d0 = r0[x0 + c] * a0 + r0[x1 + c] * a1;
+      const int d1 = r1[x0 + c] * a0 + r1[x1 + c] * a1;
+      r3[c] = (float)(unsigned char)((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2);
+    }
   } else if (sc.fast_x > 0) {  // resizeAreaFast_: integer scale; 2x2 rounds half up, other areas go through float * (1.f/area)
     int sum[3] = {0, 0, 0};
     for (int yy = 0; yy < sc.fast_y; ++yy)

@@ -44,24 +44,42 @@ void area_tab(int ssize, int dsize, double scale, std::vector<AreaTab>& tab) {
   }
 }
 
+// cv::resize(INTER_AREA) when an axis is ENLARGED (display resolution smaller than a pyramid level): OpenCV implements true area
+// interpolation only for scale_x >= 1 && scale_y >= 1 and otherwise runs its bilinear kernel with `area_mode` coefficients:
+//   sx = cvFloor(dx * scale); fx = (float)((dx + 1) - (sx + 1) * inv_scale); fx = fx <= 0 ? 0 : fx - cvFloor(fx)
+// (source index clamped at both ends with fx = 0), 11-bit fixed-point weights saturate_cast<short>(w * 2048), HResizeLinear into int
+// rows and the u8 VResizeLinear  dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  Restated independently in
+// tests/_cvref.py; the device path (preproc.hip) uses the tables built here.
+void linear_area_tab(int ssize, int dsize, std::vector<int>* tab /* [dsize][4]: s0, s1, a0, a1 */) {
+  const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
+  tab->assign((size_t)dsize * 4, 0);
+  for (int d = 0; d < dsize; ++d) {
+    int sx = (int)std::floor(d * scale);
+    float fx = (float)((d + 1) - (sx + 1) * inv_scale);
+    fx = fx <= 0 ? 0.f : fx - std::floor(fx);
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+    const float c0 = 1.f - fx, c1 = fx;
+    auto sat_short = [](float v) { const int q = cv_round(v); return q < -32768 ? -32768 : (q > 32767 ? 32767 : q); };
+    int* t = tab->data() + (size_t)d * 4;
+    t[0] = sx; t[1] = std::min(sx + 1, ssize - 1); t[2] = sat_short(c0 * 2048.f); t[3] = sat_short(c1 * 2048.f);
+  }
+}
+
 void resize_linear_u8(const unsigned char* src, int sw, int sh, unsigned char* dst, int dw, int dh) {
-  // enlarging fallback (only reached when the display resolution is smaller than the net input)
+  std::vector<int> xt, yt;
+  linear_area_tab(sw, dw, &xt);
+  linear_area_tab(sh, dh, &yt);
   for (int y = 0; y < dh; ++y) {
-    const float fy = (float)((y + 0.5) * sh / dh - 0.5);
-    int y0 = (int)std::floor(fy);
-    const float wy = fy - y0;
-    const int y1 = std::min(std::max(y0 + 1, 0), sh - 1);
-    y0 = std::min(std::max(y0, 0), sh - 1);
+    const int* ty = yt.data() + (size_t)y * 4;
+    const unsigned char* r0 = src + (size_t)ty[0] * sw * 3;
+    const unsigned char* r1 = src + (size_t)ty[1] * sw * 3;
     for (int x = 0; x < dw; ++x) {
-      const float fx = (float)((x + 0.5) * sw / dw - 0.5);
-      int x0 = (int)std::floor(fx);
-      const float wx = fx - x0;
-      const int x1 = std::min(std::max(x0 + 1, 0), sw - 1);
-      x0 = std::min(std::max(x0, 0), sw - 1);
+      const int* tx = xt.data() + (size_t)x * 4;
       for (int c = 0; c < 3; ++c) {
-        const float a = src[(y0 * sw + x0) * 3 + c] * (1 - wx) + src[(y0 * sw + x1) * 3 + c] * wx;
-        const float b = src[(y1 * sw + x0) * 3 + c] * (1 - wx) + src[(y1 * sw + x1) * 3 + c] * wx;
-        dst[(y * dw + x) * 3 + c] = sat_u8(cv_round(a * (1 - wy) + b * wy));
+        const int d0 = r0[tx[0] * 3 + c] * tx[2] + r0[tx[1] * 3 + c] * tx[3];
+        const int d1 = r1[tx[0] * 3 + c] * tx[2] + r1[tx[1] * 3 + c] * tx[3];
+        dst[((size_t)y * dw + x) * 3 + c] = (unsigned char)((((ty[2] * (d0 >> 4)) >> 16) + ((ty[3] * (d1 >> 4)) >> 16) + 2) >> 2);
       }
     }
   }
@@ -197,6 +215,7 @@ void warp_scale_cubic_u8(const unsigned char* src, int sw, int sh, double scale,
 // shared with the device path (engine.cpp uploads exactly these tables)
 void rtp_internal_cubic_tab2d(short* tab) { cubic_tab2d(tab); }
 double rtp_internal_warp_inverse_scale(double s) { return warp_inverse_scale(s); }
+void rtp_internal_linear_area_table(int ssize, int dsize, std::vector<int>* tab) { linear_area_tab(ssize, dsize, tab); }
 int rtp_internal_area_table(int ssize, int dsize, std::vector<int>* start, std::vector<int>* si, std::vector<float>* alpha) {
   if (dsize > ssize) return -1;  // enlarging: the host path falls back to linear interpolation
   std::vector<AreaTab> tab;

@@ -121,12 +121,51 @@ def _area_tab(ssize, dsize, scale):
     return tab
 
 
+def _linear_area_tab(ssize, dsize):
+    """cv::resize's coefficient loop in `area_mode` (INTER_AREA asked for, but an axis is enlarged: "true area interpolation is only
+    implemented for scale_x >= 1 && scale_y >= 1; in other cases it is emulated using some variant of bilinear interpolation"):
+    sx = cvFloor(dx * scale); fx = (float)((dx + 1) - (sx + 1) * inv_scale); fx = fx <= 0 ? 0 : fx - cvFloor(fx); the source index is
+    clamped at both ends with fx = 0; 11-bit fixed-point weights saturate_cast<short>(w * INTER_RESIZE_COEF_SCALE).
+    Returns (s0, s1, a0, a1) int arrays of length dsize (s1 = the right / lower neighbour, clipped)."""
+    inv_scale = dsize / float(ssize)
+    scale = 1.0 / inv_scale
+    s0 = np.zeros(dsize, np.int64); s1 = np.zeros(dsize, np.int64); a0 = np.zeros(dsize, np.int64); a1 = np.zeros(dsize, np.int64)
+    for d in range(dsize):
+        sx = int(np.floor(d * scale))
+        fx = np.float32((d + 1) - (sx + 1) * inv_scale)
+        fx = np.float32(0) if fx <= 0 else np.float32(fx - np.floor(fx))
+        if sx < 0:
+            fx, sx = np.float32(0), 0
+        if sx >= ssize - 1:
+            fx, sx = np.float32(0), ssize - 1
+        c0, c1 = np.float32(np.float32(1) - fx), fx
+        a0[d] = int(np.clip(np.rint(np.float32(c0 * np.float32(2048))), -32768, 32767))
+        a1[d] = int(np.clip(np.rint(np.float32(c1 * np.float32(2048))), -32768, 32767))
+        s0[d], s1[d] = sx, min(sx + 1, ssize - 1)
+    return s0, s1, a0, a1
+
+
+def resize_area_enlarging(img, dw, dh):
+    """cv::resize(img, (dw, dh), 0, 0, INTER_AREA) where at least one axis is enlarged, 8UC3: resizeGeneric_ with HResizeLinear (int
+    rows: S[s0] a0 + S[s1] a1, weights scaled by 2048) and the u8 specialisation of VResizeLinear:
+    dst = (((b0 * (row0 >> 4)) >> 16) + ((b1 * (row1 >> 4)) >> 16) + 2) >> 2."""
+    sh, sw, _ = img.shape
+    x0, x1, a0, a1 = _linear_area_tab(sw, dw)
+    y0, y1, b0, b1 = _linear_area_tab(sh, dh)
+    S = img.astype(np.int64)
+    rows = S[:, x0] * a0[None, :, None] + S[:, x1] * a1[None, :, None]            # [sh][dw][3]
+    r0, r1 = rows[y0], rows[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return (out & 0xff).astype(np.uint8)                                           # uchar(...) cast
+
+
 def resize_area(img, dw, dh):
-    """cv::resize(img, (dw, dh), 0, 0, INTER_AREA) for an HxWx3 uint8 image with dw <= W and dh <= H."""
+    """cv::resize(img, (dw, dh), 0, 0, INTER_AREA) for an HxWx3 uint8 image."""
     sh, sw, _ = img.shape
     if (dw, dh) == (sw, sh):
         return img.copy()
-    assert dw <= sw and dh <= sh
+    if dw > sw or dh > sh:
+        return resize_area_enlarging(img, dw, dh)
     scale_x = 1.0 / (dw / float(sw))
     scale_y = 1.0 / (dh / float(sh))
     ix, iy = int(np.rint(scale_x)), int(np.rint(scale_y))
@@ -166,8 +205,10 @@ def producer_frame(img, disp_w, disp_h, net_w, net_h, num_scales, start_scale, s
     disp = warp_affine_scale_cubic(img, s, disp_w, disp_h)
     outs = []
     for i in range(num_scales):
-        sc = np.float32(start_scale) - np.float32(i) * np.float32(scale_gap)    # float scale = START_SCALE - i*SCALE_GAP
-        tw = int(16 * np.ceil(net_w * float(sc) / 16))
-        th = int(16 * np.ceil(net_h * float(sc) / 16))
+        sc = np.float32(float(start_scale) - i * float(scale_gap))             # float scale = START_SCALE - i*SCALE_GAP (double flags, rtpose.cpp:360)
+        # target_width = 16 * ceil(NET_RESOLUTION_WIDTH * scale / 16): int * float is FLOAT arithmetic — 320 * 0.6f is exactly 192.0f and
+        # the level is 192 wide; in double it would be 192.0000076 -> 208 (found by the round-5 geometry with scale_gap 0.4)
+        tw = int(16 * np.ceil(np.float32(np.float32(net_w) * sc) / np.float32(16)))
+        th = int(16 * np.ceil(np.float32(np.float32(net_h) * sc) / np.float32(16)))
         outs.append(pad(resize_area(disp, tw, th), net_w, net_h, 1))
     return np.stack(outs), disp, np.float32(s)

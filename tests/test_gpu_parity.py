@@ -464,20 +464,24 @@ def test_submit_frame_equals_host_preprocess_plus_submit():
     e.close()
 
 
-def test_submit_frame_enlarging_level_falls_back_to_host_restatement():
-    """display smaller than the net input: the INTER_AREA level would enlarge; the engine then
-    runs the host restatement (linear branch) — still the same numbers as rtp_preprocess_frame."""
+def test_submit_frame_with_an_enlarging_pyramid_level_runs_on_the_device():
+    """display smaller than the net input: cv::resize(INTER_AREA) then enlarges with its bilinear kernel and area-mode coefficients
+    (tests/_cvref.py resize_area_enlarging).  Round 5: that level runs on the device too (round 4: host fallback) — same numbers as
+    rtp_preprocess_frame, which equals the independent restatement (test_host_preprocess_equals_independent_opencv_restatement)."""
     import caffe_rtpose_amd as r
-    e = _engine(net_w=160, net_h=96, num_scales=1, disp_w=120, disp_h=80, frames_in_flight=1)
+    import _cvref
+    e = _engine(net_w=160, net_h=96, num_scales=2, scale_gap=0.4, disp_w=120, disp_h=80, frames_in_flight=1)   # level 0 enlarges (160x96 from 120x80), level 1 shrinks (96x64)
     img = r.synth_frame(320, 240, 1, seed=9)
-    x, _, fs = r.preprocess_frame(img, 120, 80, 160, 96, 1, 1.0, 0.3)
+    x, disp, fs = r.preprocess_frame(img, 120, 80, 160, 96, 2, 1.0, 0.4)
+    want_x, want_disp, want_fs = _cvref.producer_frame(img, 120, 80, 160, 96, 2, 1.0, 0.4, orc.process_and_pad_image)
+    assert np.array_equal(x, want_x) and np.array_equal(disp, want_disp) and fs == want_fs
+    gx, gdisp, gfs = e.debug_preprocess(img)
+    assert gfs == fs and np.array_equal(gdisp, disp) and np.array_equal(gx, x)
     e.submit(x, tag=5)
     want = e.collect()
     fs2 = e.submit_frame(img, tag=5)
     got = e.collect()
     assert fs2 == fs and got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
-    with pytest.raises(r.RtpError):
-        e.debug_preprocess(img)
     e.close()
 
 
@@ -776,7 +780,8 @@ def test_ring_kernel_variants_are_bit_identical():
     assert strip(run(RTP_LIB=exp)) == strip(base)                                # the experiments build without knobs = the production bits
     assert strip(run(RTP_LIB=exp, RTP_RING_ILV="1")) == strip(base)
     assert strip(run(RTP_LIB=exp, RTP_HALO_SHARED="0")) == strip(base)
-    assert strip(run(RTP_LIB=exp, RTP_PREP_DEFER="0")) == strip(base)             # rtp_submit's copy on the conv stream (round 3) vs on the copy-only stream (default)
+    assert strip(run(RTP_LIB=exp, RTP_PREP_DEFER="1")) == strip(base)             # the copy-only stream + deferred pre-processing kernels (an experiment: prep_defer defaults to 0,
+                                                                                  # copies and kernels stay on the batch's conv stream) vs the default
     assert strip(run(RTP_RING_VAR="12", RTP_DIAG_SKIP_POST="2")) == strip(base)  # the production library does not know these names
 
 

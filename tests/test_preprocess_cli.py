@@ -374,6 +374,10 @@ GEOMS = [  # (frame w, h, display w, h, net w, h, scales, start, gap)
     (720, 1280, 720, 1280, 368, 656, 2, 0.8, 0.15),    # portrait frame, display and net
     (1920, 1080, 1920, 1080, 1312, 736, 2, 0.8, 0.15), # large net (low-res 92 x 164)
     (1312, 736, 1312, 736, 656, 368, 2, 0.5, 0.25),    # display = 4x / 8x the target: resizeAreaFast_ at start_scale 0.5
+    # --resolution smaller than a pyramid level: cv::resize(INTER_AREA) enlarges with its bilinear kernel and area-mode coefficients
+    (640, 360, 320, 180, 656, 368, 2, 1.0, 0.3),       # both axes enlarged at both levels (656x368, 464x272 from 320x180)
+    (500, 375, 800, 200, 320, 240, 2, 1.0, 0.4),       # mixed: x shrinks (800 -> 320 / 192), y grows (200 -> 240) at level 0, shrinks at level 1 (144)
+    (333, 201, 123, 77, 160, 96, 1, 1.0, 0.3),         # odd sizes
 ]
 
 
