@@ -777,11 +777,14 @@ static hipError_t ring_launch_cfg(int cfg, int chb, const ConvParams& P, int npr
       // 56 KiB of LDS and <= 128 registers: two workgroups (of different frames) share a CU
       return ring_launch_one<T, 64, 64, 1, 1, 4, KS, 128, 4, 2>(P, nprob, N, stream);
     case CFG_128x64: return ring_launch_one<T, 128, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);
+#ifdef RTP_EXPERIMENTS
     case CFG_256x64:
       // 256 pixels x 64 output channels per workgroup, 128-byte chunks: the K loop of the 128x64 / 256-byte tile (16 MFMAs per wave
       // and step) over twice as many steps — one pipeline fill and one epilogue per 98 K steps instead of 49.  fp16 7x7 layers only.
+      // Measured (profiles/r05_experiments.txt): faster alone, no gain in the pipeline: experiments build only.
       if constexpr (std::is_same<T, _Float16>::value && KS == 7) return ring_launch_one<T, 256, 64, 2, 1, 2, KS, 128, 4>(P, nprob, N, stream);
       else return hipErrorInvalidValue;
+#endif
     default: return hipErrorInvalidValue;
   }
 }

@@ -587,7 +587,12 @@ int build_plan(rtp_engine* e) {
     else if (maxcout <= 64) cands = {CFG_128x64, CFG_64x64};
     else if (ring_ok && row_bytes_all % 256 == 0) {
       cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64, CFG_128x32};
-      if (e->prec == 0 && A.k_eff == 7 && maxcout >= 64) cands.push_back(CFG_256x64);   // (chosen by the model where 128-pixel tiles would need two rounds: batches of >= 4 images)
+      // CFG_256x64 (round 5): twice the pixels per workgroup for the 7x7 layers.  Alone at batches of 4 it is 12-14 % faster per image than the
+      // 128x64 tile at batches of 2; in the PIPELINE it changes nothing (B = 4: 1012 vs 1006 frames/s against 128x128 tiles, MPI B = 5: 1209 vs
+      // 1207; profiles/r05_experiments.txt), so the production plans keep round 4's measured tiles and the candidate exists in the experiments
+      // build only (RTP_TILE_256=1: let the time model choose it; RTP_DOM_256 forces it).
+      static const char* t256 = RTP_EXP_ENV("RTP_TILE_256");
+      if (e->prec == 0 && A.k_eff == 7 && maxcout >= 64 && ((t256 && t256[0] == '1') || RTP_EXP_ENV("RTP_DOM_256"))) cands.push_back(CFG_256x64);   // (chosen by the model where 128-pixel tiles would need two rounds: batches of >= 4 images)
     }
     else if (ring_ok) cands = {CFG_128x128, CFG_64x128, CFG_128x64, CFG_64x64};
     else cands = {CFG_128x128, CFG_64x128, CFG_64x64};

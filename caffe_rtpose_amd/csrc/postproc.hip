@@ -533,22 +533,37 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
         ytab[tid].o0 = (yn[0] - rlo) * W; ytab[tid].o1 = (yn[1] - rlo) * W; ytab[tid].o2 = (yn[2] - rlo) * W; ytab[tid].o3 = (yn[3] - rlo) * W;
       }
       __syncthreads();
-      for (int x = tid; x < W; x += 256) {
-        if (col_skip && xt[x].xn1 < 0) {  // (one scale: this is the final value)
-          for (int yy = 0; yy < nrow; ++yy) out[yy * W + x] = p.threshold;
-          continue;
+      // (round 5) a thread's columns x, x + 256, x + 512 are evaluated TOGETHER, row by row: the rows of one low-res cell share the row's
+      // table entry and the branch on it (uniform), and three independent cubic_eval chains are in flight instead of one — the phase was a
+      // latency chain (5.2 of the workgroup's 21 us for ~26 evaluations per thread).  Same operations on the same values.
+      constexpr int XI = 3;
+      for (int xb = tid; xb < W; xb += 256 * XI) {
+        int xs[XI];
+        bool act[XI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          xs[i] = xb + i * 256;
+          act[i] = xs[i] < W;
+          if (act[i] && col_skip && xt[xs[i]].xn1 < 0) {  // (one scale: this is the final value)
+            for (int yy = 0; yy < nrow; ++yy) out[yy * W + xs[i]] = p.threshold;
+            act[i] = false;
+          }
+          if (!act[i]) xs[i] = 0;   // (a safe column for the unconditional loads below; its results are not stored)
         }
         int prev = -1;
-        CubicCoef k;
+        CubicCoef k[XI];
         for (int yy = 0; yy < nrow; ++yy) {
           const YTab yt = ytab[yy];
           if (yt.o1 != prev) {
             prev = yt.o1;
-            k = cubic_coef(T[yt.o0 + x], T[yt.o1 + x], T[yt.o2 + x], T[yt.o3 + x]);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) k[i] = cubic_coef(T[yt.o0 + xs[i]], T[yt.o1 + xs[i]], T[yt.o2 + xs[i]], T[yt.o3 + xs[i]]);
           }
-          const float d = cubic_eval(k, yt.dy);
-          float* o = out + yy * W + x;
-          *o = (n == 0 ? 0.f : *o) + d;
+          float d[XI], prevv[XI];
+#pragma unroll
+          for (int i = 0; i < XI; ++i) { d[i] = cubic_eval(k[i], yt.dy); prevv[i] = n == 0 ? 0.f : out[yy * W + xs[i]]; }
+#pragma unroll
+          for (int i = 0; i < XI; ++i) if (act[i]) out[yy * W + xs[i]] = prevv[i] + d[i];
         }
       }
       __syncthreads();
@@ -574,66 +589,70 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
     for (int i = tid; i < nrow * W; i += 256) out[i] = out[i] / r.num;
     __syncthreads();
   }
-  const int npix = (y1 - y0) * W;
-  const int pix0 = y0 * W;
   int* list = p.strip_list + ((long)part * p.nstrips + strip) * p.max_peaks;
   const float* s = out - (long)ya * W;  // s[y * W + x] for y in ya..yb
-  // Raster-order ordinals with two barriers: wave w owns the w-th quarter of the strip's pixels
-  // (64-pixel groups, contiguous), keeps one ballot per group in LDS (T is free now) and counts;
-  // after the wave totals are exchanged every maximum knows its ordinal.
-  unsigned long long* bals = (unsigned long long*)T;
-  const int ngroups = (npix + 63) / 64;
-  const int gper = (ngroups + 3) / 4;
-  const int g0 = wave * gper, g1 = min(g0 + gper, ngroups);
-  int mine = 0;
+  // nms_register_kernel, nms_layer.cu:15-46, in raster order.  Round 5: a lane owns ONE column of a 64-column block and walks down the strip's
+  // rows with the 3x3 window in registers (3 LDS reads per pixel instead of 9: the phase was 6 of the workgroup's 21 us); one ballot per
+  // (row, block) = 64 consecutive pixels of a row, so the groups in (row, block) order ARE raster order.  T is free now: ballots and
+  // their exclusive prefix live there.
+  const int NG = (W + 63) >> 6;                 // 64-column blocks per row
+  const int nr = y1 - y0;                       // rows of this strip
+  const int ngr = nr * NG;
+  unsigned long long* bals = (unsigned long long*)T;      // [nr][NG]
+  int* gbase = (int*)(bals + ngr);                        // [ngr + 1]: flags in front of group g (raster order)
   {
-    // nms_register_kernel, nms_layer.cu:15-46.  All nine values of a pixel are read unconditionally and three groups are in
-    // flight per iteration: the loop was a chain of dependent LDS round trips (6.2 of a workgroup's 21 us, RTP_NMS_PROBE).
-    int q = g0 * 64 + lane;            // this lane's pixel of group g, as (x, y) without a division per group
-    int py = y0 + q / W, px = q % W;
     const float thr = p.threshold;
-    auto flag_at = [&](int qq, int x, int y) __attribute__((always_inline)) {
-      const bool in = qq < npix && x > 0 && x < W - 1 && y > 0 && y < H - 1;
-      const float* c = s + (in ? y * W + x : ya * W + 1 + W);   // any interior address when out of range (nrow >= 2 there or the flag is dropped)
-      const float v = c[0], top = c[-W], bottom = c[W], left = c[-1], right = c[1];
-      const float tl = c[-W - 1], tr = c[-W + 1], bl = c[W - 1], br = c[W + 1];
-      return in && v > thr && v > top && v > bottom && v > left && v > right && v > tl && v > bl && v > br && v > tr;
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-      q += 64;
-      px += 64;
-      while (px >= W) { px -= W; ++py; }
-    };
-    int g = g0;
-    for (; g + 2 < g1; g += 3) {
-      const int qa = q, xa_ = px, ya_ = py; advance();
-      const int qb = q, xb_ = px, yb_ = py; advance();
-      const int qc = q, xc_ = px, yc_ = py; advance();
-      const bool fa = flag_at(qa, xa_, ya_), fb = flag_at(qb, xb_, yb_), fc = flag_at(qc, xc_, yc_);
-      const unsigned long long ba = __ballot(fa), bb = __ballot(fb), bc = __ballot(fc);
-      if (lane == 0) { bals[g] = ba; bals[g + 1] = bb; bals[g + 2] = bc; }
-      mine += __popcll(ba) + __popcll(bb) + __popcll(bc);
-    }
-    for (; g < g1; ++g) {
-      const bool f = flag_at(q, px, py);
-      const unsigned long long bal = __ballot(f);
-      if (lane == 0) bals[g] = bal;
-      mine += __popcll(bal);
-      advance();
+    for (int c = wave; c < NG; c += 4) {
+      const int x = (c << 6) + lane;
+      const bool xin = x > 0 && x < W - 1;
+      const int xc = xin ? x : 1;               // any interior column when out of range (the flag is dropped)
+      auto rowp = [&](int yy) __attribute__((always_inline)) { return s + (long)(yy < ya ? ya : (yy > yb ? yb : yy)) * W + xc; };
+      const float* pa = rowp(y0 - 1);
+      const float* pb = rowp(y0);
+      float a0 = pa[-1], a1 = pa[0], a2 = pa[1];
+      float b0 = pb[-1], b1 = pb[0], b2 = pb[1];
+      for (int y = y0; y < y1; ++y) {
+        const float* pc = rowp(y + 1);
+        const float c0 = pc[-1], c1 = pc[0], c2 = pc[1];
+        const bool in = xin && y > 0 && y < H - 1;
+        const float v = b1;
+        const bool f = in && v > thr && v > a1 && v > c1 && v > b0 && v > b2 && v > a0 && v > c0 && v > c2 && v > a2;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) bals[(y - y0) * NG + c] = bal;
+        a0 = b0; a1 = b1; a2 = b2;
+        b0 = c0; b1 = c1; b2 = c2;
+      }
     }
   }
-  if (lane == 0) wave_cnt[wave] = mine;
   __syncthreads();
   NMS_STAMP();  // 7: flags + ballots
-  int ord0 = 0;
-  for (int w = 0; w < wave; ++w) ord0 += wave_cnt[w];
-  for (int g = g0; g < g1 && ord0 < p.max_peaks; ++g) {
-    const unsigned long long bal = bals[g];
-    const int ord = ord0 + __popcll(bal & ((1ull << lane) - 1ull));
-    if (((bal >> lane) & 1) && ord < p.max_peaks) list[ord] = pix0 + g * 64 + lane;
-    ord0 += __popcll(bal);
+  if (wave == 0) {   // exclusive prefix of the groups' flag counts, 64 groups per step
+    int run = 0;
+    for (int g0 = 0; g0 < ngr; g0 += 64) {
+      const int g = g0 + lane;
+      const int cnt = g < ngr ? __popcll(bals[g]) : 0;
+      int inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      if (g < ngr) gbase[g] = run + inc - cnt;
+      run += __shfl(inc, 63);
+    }
+    if (lane == 0) { gbase[ngr] = run; p.strip_count[part * p.nstrips + strip] = run; }
   }
-  if (tid == 0) p.strip_count[part * p.nstrips + strip] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  __syncthreads();
+  for (int g = wave; g < ngr; g += 4) {
+    const int base = gbase[g];
+    if (base >= p.max_peaks) break;             // prefixes grow with g: nothing further fits under the cap
+    const unsigned long long bal = bals[g];
+    const int ord = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (((bal >> lane) & 1) && ord < p.max_peaks) {
+      const int r = g / NG, c = g - r * NG;
+      list[ord] = (y0 + r) * W + (c << 6) + lane;
+    }
+  }
   NMS_STAMP();  // 8: list
   if (probe_me && tid == 0) p.probe[0] = stamp_i;
 }

@@ -203,7 +203,8 @@ def replay(model, res_r, res_e, kr, ke, mr, pk_r, pk_e, tr, te, max_peaks, net_w
     # ---- stage 1: the engine's flag set on the reference's map ------------------------------------------------------------------
     for p in range(num_parts):
         for (y, x) in set(kr[p]) ^ set(ke[p]):
-            check("nms", abs(mr[p, y, x]), 2 * e_heat, f"part {p} pixel ({x},{y}): reference margin {mr[p, y, x]:+.3e}")
+            loc = float(np.abs(res_e[p, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2].astype(np.float64) - res_r[p, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2]).max())
+            check("nms", abs(mr[p, y, x]), 2 * loc * (1 + 1e-6) + 1e-12, f"part {p} pixel ({x},{y}): reference margin {mr[p, y, x]:+.3e}, local deviation {loc:.3e}")
     pk_c = peaks_at(res_r, ke, max_peaks, num_parts)
     counts = [min(len(k), max_peaks) for k in ke]
     e_pos = e_sc = 0.0
