@@ -19,15 +19,20 @@ repeated with more frames until it is long enough, and the line reports the fram
 as `steps_requested`) with `timed_region_s`.  Defaults per workload are measured optima (profiles/r03_in_flight.txt): COCO 1 scale 7
 frames in flight in batches of 2, several scales 3 in flight one frame per launch sequence, MPI 10 in flight in batches of 5.
 
-`roofline` (separate pass right after the timed region): HIP event pairs around every launch of the dominant kernel shape, on the stream
-the launch runs on, one batch at a time — roofline_block() below; `parity`: the engine's joints against the full fp32 oracle chain as
-sets of people, every structural difference traced to the decision that flipped (tests/_parity.py, tests/_explain.py), plus the
-structured leg: planted people + the engine's measured deviation field through both post-processing chains; `cpu_baseline`: the
+`roofline` (separate pass right after the timed region): HIP event pairs around EVERY launch of a batch, on the stream the launch runs on,
+one batch at a time — the dominant kernel shape's launches give achieved / frac (roofline_block() below), all launches grouped by kernel class
+give `roofline.classes` (kernel_classes()); `gpu_busy`: an unprofiled account of when the engine had work on the GPU (rtp_busy_probe,
+busy_account()); `parity`: the engine's joints against the full fp32 oracle chain as sets of people, every structural difference traced to
+the decision that flipped (tests/_parity.py, tests/_explain.py) AND reproduced by a counterfactual replay of the reference chain with only
+those near-tie decisions forced (tests/_replay.py: `replay_identical`), plus the structured leg: planted people + the engine's measured
+deviation field through both post-processing chains; `cpu_baseline`: the
 OpenMP oracle port and torch-CPU conv2d over the same layers; `latency_ms.p50_single_frame`: one frame alone, commit -> joints on the
 host (rtpose.cpp:1430).
 
 On one GPU the line also carries `sub_results`: resident input, MPI 496x368 (BASELINE configs[4], with its own roofline and parity),
-3 scales (configs[2], the north-star target), single-pass fp16, the exact-f32 path, post-processing alone on analytic heat maps.
+3 scales (configs[2], the north-star target, with its own roofline and parity), single-pass fp16, the exact-f32 path, post-processing alone
+on analytic heat maps.  Every leg's headline scalar is repeated as `roofline.leg_*` and in the trailing `summary` object (the LAST key of
+the line), so a record that truncates the line or keeps only `roofline` still shows them.
 """
 import argparse
 import glob
@@ -708,8 +713,8 @@ def main():
     roof = roofline_pass(eng, frames, args.batch_frames, args.precision, args.num_scales, args.model)
     stage = eng.last_stage_ms()
     busy = None
-    if rank == 0:   # the same pipelined loop once more with the busy probe on (~0.5 s): when did the engine have work on the GPU — no profiler attached
-        try:
+    if True:        # the same pipelined loop once more with the busy probe on (~0.5 s): when did the engine have work on the GPU — no profiler attached.
+        try:        # EVERY rank runs it (measure() holds the ranks' barrier and reductions); rank 0's account goes into the line
             eng.busy_probe(1)
             mb = measure(eng, submit, 200, 20, args.in_flight, 0.5)
             busy = busy_account(eng.busy_probe(-1))

@@ -134,7 +134,10 @@ int rtp_get_thresholds(const rtp_engine* e, float* nms_threshold, float* connect
                        int* connect_inter_min_above_threshold, int* connect_min_subset_cnt,
                        float* connect_min_subset_score);
 
-/* Replaces: ImResizeLayer::SetStartScale/SetScaleGap (imresize_layer.hpp:11-45). */
+/* Replaces: ImResizeLayer::SetStartScale/SetScaleGap (imresize_layer.hpp:11-45).  Every level s = start_scale - i * scale_gap
+ * (i < num_scales) must be positive and its 16-aligned size 16 * ceil(net * s / 16) must fit the net input — what the producer CHECKs
+ * (rtpose.cpp:363-364) — else RTP_EINVAL and the engine keeps its previous scales; the same test guards rtp_engine_create and
+ * rtp_preprocess_frame.  start_scale < 1 is in contract: ImResize then crops every scale incl. the first (imresize_layer.cu:110-113). */
 int rtp_set_scales(rtp_engine* e, float start_scale, float scale_gap);
 
 /* ---- the per-frame hot loop (rtpose.cpp:1127-1166) ---------------------------------- */

@@ -116,6 +116,11 @@ def test_cli_flag_errors_and_no_device_exit_code(tmp_path):
     assert p.returncode == 1 and b"resolution format" in p.stderr
     p = subprocess.run([BIN], capture_output=True)
     assert p.returncode == 1 and b"camera" in p.stderr
+    # --start_scale / --scale_gap / --net_resolution out of contract (the reference CHECKs, rtpose.cpp:363): an error exit with the reason,
+    # with or without a GPU (argument errors come before the device is touched)
+    for bad in (["--start_scale", "1.3"], ["--start_scale", "0.5", "--scale_gap", "0.25", "--num_scales", "3"], ["--net_resolution", "100x64"]):
+        p = subprocess.run([BIN, "--video", "synthetic:64x48:2", "--model", "coco", "--net_resolution", "64x48", "--write_json", str(tmp_path / "bad")] + bad, capture_output=True)
+        assert p.returncode == 1 and (b"does not fit the net resolution" in p.stderr or b"multiples of 16" in p.stderr), (bad, p.stderr[-300:])
     import torch
     if not torch.cuda.is_available():
         p = subprocess.run([BIN, "--video", "synthetic:64x48:2", "--model", "coco", "--net_resolution", "64x48",
@@ -145,6 +150,32 @@ def test_cli_json_matches_library_path(tmp_path):
         assert want == orc.write_json(d["joints"], d["num_people"], 18, fs)
         assert open(out / files[i], "rb").read() == want
     e.close()
+
+
+@pytest.mark.gpu
+def test_cli_start_scale_and_a_display_smaller_than_the_net(tmp_path):
+    """--start_scale (rtpose.cpp:68) below 1 with several scales, and --resolution smaller than --net_resolution (the first pyramid level is
+    ENLARGED: OpenCV's area-mode bilinear kernel, on the device since round 5): the CLI's JSON equals the library path fed by the HOST
+    restatement of the producer (which equals the independent OpenCV restatement, tests/_cvref.py); out-of-contract scales exit with an error."""
+    import caffe_rtpose_amd as r
+    out = tmp_path / "js"
+    flags = ["--model", "coco", "--net_resolution", "160x96", "--resolution", "128x80", "--num_scales", "3", "--start_scale", "0.9", "--scale_gap", "0.2",
+             "--no_frame_drops", "--no_display", "--num_gpu", "1"]
+    p = subprocess.run([BIN, "--video", "synthetic:640x480:5:7", "--write_json", str(out)] + flags, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    e = r.Engine(r.Config(net_w=160, net_h=96, num_scales=3, start_scale=0.9, scale_gap=0.2, disp_w=128, disp_h=80, frames_in_flight=1))
+    people = 0
+    for i in range(5):
+        img = r.synth_frame(640, 480, i, seed=7)
+        x, _, fs = r.preprocess_frame(img, 128, 80, 160, 96, 3, 0.9, 0.2)      # levels 0.9 (160x96 from 128x80: enlarged), 0.7, 0.5
+        d = e.forward_debug(x)
+        people += d["num_people"]
+        assert open(out / f"frame{i:06d}.json", "rb").read() == r.format_json(d["joints"], d["num_people"], 18, fs), i
+    e.close()
+    for bad in (["--start_scale", "1.3"], ["--start_scale", "0.5", "--scale_gap", "0.25"], ["--start_scale", "0"]):   # a level above the net / a level of scale 0
+        q = subprocess.run([BIN, "--video", "synthetic:640x480:2:7", "--write_json", str(tmp_path / "bad")] + [a for a in flags if a not in ("--start_scale", "0.9", "--scale_gap", "0.2")] + bad,
+                           capture_output=True, timeout=120)
+        assert q.returncode != 0 and b"does not fit the net resolution" in q.stderr, (bad, q.stderr[-300:])
 
 
 def test_cpp_net_api_mirror_compiles_and_links(tmp_path):
