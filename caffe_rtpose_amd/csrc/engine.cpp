@@ -1442,6 +1442,21 @@ int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   HIPCHK(e, hipMalloc((void**)&sl.num_people, sizeof(int)));
   HIPCHK(e, hipHostMalloc((void**)&sl.host_out, (jfloats + 4) * sizeof(float), hipHostMallocDefault));
   for (int i = 0; i < 5; ++i) HIPCHK(e, hipEventCreate(&sl.ev[i]));
+  // Staging buffers of rtp_submit_frame for frames up to the display size (a video at --resolution, BASELINE configs[1]) and the renderer's
+  // buffers are allocated HERE, under the creation lock: the per-frame path then never allocates (and never takes g_sync_mutex) unless a
+  // frame is larger than the display image.
+  {
+    const size_t fbytes = (size_t)e->cfg.disp_w * e->cfg.disp_h * 3;
+    HIPCHK(e, hipMalloc((void**)&sl.frame_dev, fbytes));
+    HIPCHK(e, hipHostMalloc((void**)&sl.frame_host, fbytes, hipHostMallocDefault));
+    sl.frame_cap = fbytes;
+    HIPCHK(e, hipMalloc((void**)&sl.disp_dev, fbytes));
+    if (e->cfg.render) {
+      HIPCHK(e, hipMalloc((void**)&sl.render_dev, fbytes));
+      HIPCHK(e, hipHostMalloc((void**)&sl.render_host, fbytes, hipHostMallocDefault));
+      HIPCHK(e, hipMalloc((void**)&sl.render_tab, render_tab_floats(RTP_MAX_PEOPLE) * sizeof(float)));
+    }
+  }
   return RTP_OK;
 }
 
