@@ -248,3 +248,59 @@ def test_roofline_timing_is_plausible_and_matches_the_step_profile():
         e.submit(x, tag=j)
     assert [e.collect()[0] for _ in range(B)] == [0, 1]
     e.close()
+
+
+def test_per_step_timing_and_busy_probe_feed_the_bench_line():
+    """rtp_kernel_timing(3) brackets EVERY step of a full batch (bench.py's `roofline.classes`), rtp_busy_probe reads the per-stream busy spans of
+    the pipelined loop at collect time (`gpu_busy`): the step rows line up with rtp_plan_summary, every step was timed once per batch, the class
+    rows add up to the model's FLOPs, and the union of the spans covers most of a saturated loop."""
+    import caffe_rtpose_amd as r
+    bench = _bench_module()
+    B = 2
+    e = r.Engine(r.Config(net_w=656, net_h=368, precision=r.PREC_MIXED, frames_in_flight=6, batch_frames=B))
+    x = _synth.random_frame(1, 368, 656, seed=3)
+    for _ in range(2):
+        for j in range(B):
+            e.submit(x, tag=j)
+        for j in range(B):
+            e.collect()
+    e.kernel_timing(3)
+    nb = 8
+    for b in range(nb):
+        for j in range(B):
+            e.submit(x, tag=j)
+        for j in range(B):
+            e.collect()
+    ms, n, flops = e.kernel_timing(-1)
+    steps = e.kernel_timing_steps()
+    e.kernel_timing(0)
+    plan = [ln for ln in r.plan_summary(e.cfg).splitlines() if ln.startswith("step ")]
+    assert len(steps) == len(plan) and n == nb * 20
+    timed = [(t, k) for (t, k), ln in zip(steps, plan) if not ln.startswith("step pack")]
+    assert all(k == nb and t > 0 for t, k in timed), [(ln[:40], k) for (t, k), ln in zip(steps, plan) if k != nb]
+    classes, total = bench.kernel_classes(plan, e.conv_layers(), steps, 656, 368, B, 2.5e15)
+    fl = sum(c["tflops"] * 1e12 * c["ms_per_batch"] * 1e-3 for c in classes.values())
+    assert abs(fl / (B * 484.634e9) - 1) < 1e-3 and 1.5 < total < 4.0              # ms of launches per batch of 2 (1.97 back to back; event pairs add their dispatch)
+    dom = [c for k, c in classes.items() if k.startswith("dominant")]
+    assert len(dom) == 2 and abs(sum(c["ms_per_batch"] * 1 for c in dom) * nb - ms) < 0.05 * ms   # the dominant class's rows ARE rtp_kernel_timing's totals
+    print("\n[classes] " + "; ".join(f"{k}: {c['us_per_launch']:.1f} us {c['tflops']:.0f} TF" for k, c in classes.items()))
+    # busy probe over a pipelined loop
+    assert len(e.busy_probe(1)) == 0
+    sub = col = 0
+    while col < 120:
+        while sub < 120 and e.in_flight() < 6:
+            e.submit(x, tag=sub)
+            sub += 1
+        e.collect()
+        col += 1
+    spans = e.busy_probe(-1)
+    e.busy_probe(0)
+    assert len(spans) >= 120 + 50 and set(np.unique(spans[:, 0])) == {0.0, 1.0} and (spans[:, 2] > spans[:, 1]).all() and (spans[:, 1] >= 0).all()
+    acc = bench.busy_account(spans)
+    print(f"[busy] {acc['busy_frac']:.4f} busy, conv streams {acc['conv_streams_busy_frac']:.3f}, {acc['conv_stacks_concurrent_avg']:.2f} stacks in flight, post chains {acc['post_chains_busy_frac']:.3f}")
+    assert 0.9 < acc["busy_frac"] <= 1.0 and acc["conv_stacks_concurrent_avg"] > 1.0
+    e.submit(x, tag=1)
+    with pytest.raises(r.RtpError):       # idle engines only
+        e.busy_probe(1)
+    e.collect()
+    e.close()
