@@ -88,6 +88,40 @@ def test_preprocess_frame_layout():
         r.preprocess_frame(img, 1280, 720, 656, 368, num_scales=1, start_scale=1.2)  # CHECK_LE(target_width, NET_RESOLUTION_WIDTH)
 
 
+def test_pyramid_level_sizes_follow_the_references_float_arithmetic():
+    """`float scale = START_SCALE - i*SCALE_GAP; target_width = 16 * ceil(NET_RESOLUTION_WIDTH * scale / 16)` (rtpose.cpp:360-361): the flags are
+    doubles, `scale` is a float, and `int * float / int` is FLOAT arithmetic — at scales where net * s lands on a multiple of 16 (0.6 of 320,
+    0.75 of 656 x 368 ...) double arithmetic gives another level size.  Sweep of start scales / gaps / nets: the padded region the product
+    writes has exactly the reference's size, centred (process_and_pad_image, :239-269)."""
+    import caffe_rtpose_amd as r
+    img = np.full((45, 80, 3), 200, np.uint8)
+    checked = exact_multiples = 0
+    for W, H in ((160, 96), (320, 240), (656, 368)):
+        for start in (1.0, 0.95, 0.9, 0.85, 0.8, 0.75, 0.7, 0.65, 0.6, 0.55, 0.5):
+            for gap in (0.1, 0.15, 0.2, 0.25, 0.3, 0.4):
+                sizes = []
+                for i in range(4):
+                    s32 = np.float32(start - i * gap)
+                    if not s32 > 0:
+                        break
+                    tw = int(16 * np.ceil(np.float32(np.float32(W) * s32) / np.float32(16)))
+                    th = int(16 * np.ceil(np.float32(np.float32(H) * s32) / np.float32(16)))
+                    if tw > W or th > H:
+                        break
+                    sizes.append((tw, th))
+                    exact_multiples += int(np.ceil(float(W) * float(s32) / 16) != float(np.ceil(np.float32(np.float32(W) * s32) / np.float32(16))))   # double vs float arithmetic
+                if not sizes:
+                    continue
+                x, _, _ = r.preprocess_frame(img, 80, 45, W, H, len(sizes), start, gap)
+                for i, (tw, th) in enumerate(sizes):
+                    inside = x[i, 0] != 0
+                    ys, xs = np.nonzero(inside)
+                    assert (xs.min(), xs.max() + 1, ys.min(), ys.max() + 1) == ((W - tw) // 2, (W - tw) // 2 + tw, (H - th) // 2, (H - th) // 2 + th), (W, H, start, gap, i, tw, th)
+                    assert inside.sum() == tw * th
+                    checked += 1
+    assert checked > 300 and exact_multiples >= 1     # the sweep contains levels where double and float arithmetic disagree
+
+
 def test_ppm_and_bmp_loaders(tmp_path):
     import caffe_rtpose_amd as r
     rs = np.random.RandomState(2)
