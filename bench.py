@@ -593,12 +593,16 @@ def main():
     seed = 1
     PREC = {"fp16": r.PREC_FP16, "fp32": r.PREC_FP32, "mixed": r.PREC_MIXED, "f16x3": r.PREC_F16X3}
 
-    def make_engine(precision, num_scales, scale_gap, batch_frames, in_flight, model=None):
+    def make_engine(precision, num_scales, scale_gap, batch_frames, in_flight, model=None, receive=None):
+        """receive = (precision id, split rules) of the engine whose packed weights this one will take: created WITHOUT weights
+        (rtp_config.defer_weights), on that engine's plan."""
         mid, W, H = MODELS[model or args.model][:3]
-        return r.Engine(r.Config(device_id=local, model=mid, net_w=W, net_h=H, num_scales=num_scales, scale_gap=scale_gap, precision=PREC[precision],
-                                 frames_in_flight=in_flight, batch_frames=batch_frames, synthetic_seed=seed, split_layers=args.split_layers,
-                                 calibrate_frames=args.calibrate if precision == "mixed" else 0,
-                                 exec_mode=r.EXEC_GRAPH if args.exec_mode == "graph" else r.EXEC_EAGER))
+        kw = dict(precision=PREC[precision], split_layers=args.split_layers, calibrate_frames=args.calibrate if precision == "mixed" else 0)
+        if receive is not None:
+            kw = dict(precision=receive[0], split_layers=receive[1], calibrate_frames=-1, defer_weights=1)
+        return r.Engine(r.Config(device_id=local, model=mid, net_w=W, net_h=H, num_scales=num_scales, scale_gap=scale_gap,
+                                 frames_in_flight=in_flight, batch_frames=batch_frames, synthetic_seed=seed,
+                                 exec_mode=r.EXEC_GRAPH if args.exec_mode == "graph" else r.EXEC_EAGER, **kw))
 
     def device_frames(eng, n=8):
         # synthetic net inputs resident in HBM before the timed region (u8/256-0.5 like process_and_pad_image), in buffers of the ENGINE's runtime
@@ -686,16 +690,30 @@ def main():
         return roof
 
     mid, W, H, _, _, _, gflop = MODELS[args.model]
-    eng = make_engine(args.precision, args.num_scales, args.scale_gap, args.batch_frames, args.in_flight)
     wb = None
-    if dist is not None and args.broadcast_weights:   # one-time: every rank ends up with rank 0's packed arena (outside the timed region)
+    if dist is not None and args.broadcast_weights:
+        # one-time weight distribution (outside the timed region): rank 0 reads / generates, packs (and calibrates) ONCE; the other ranks learn its
+        # plan (precision mode + split set), are created without weights (rtp_config.defer_weights) and import rank 0's packed arena
         t0 = time.perf_counter()
+        meta = np.zeros(4096, np.uint8)
+        eng = None
+        if rank == 0:
+            eng = make_engine(args.precision, args.num_scales, args.scale_gap, args.batch_frames, args.in_flight)
+            rules, mode = eng.split_layers()
+            enc = f"{mode}|{rules}".encode()
+            meta[:len(enc)] = np.frombuffer(enc, np.uint8)
+        meta = broadcast_bytes(meta, 0, dist, red_dev)
+        if rank != 0:
+            mode, rules = bytes(meta).rstrip(b"\0").decode().split("|", 1)
+            eng = make_engine(args.precision, args.num_scales, args.scale_gap, args.batch_frames, args.in_flight, receive=(int(mode), rules))
         blob = eng.weight_blob() if rank == 0 else np.zeros(eng.weight_blob_bytes(), np.uint8)   # (non-zero ranks only need the length: no D2H copy)
         blob = broadcast_bytes(blob, 0, dist, red_dev)
         if rank != 0:
             eng.load_weight_blob(blob)
-        wb = {"bytes": int(blob.nbytes), "seconds": time.perf_counter() - t0}
+        wb = {"bytes": int(blob.nbytes), "seconds": time.perf_counter() - t0, "receivers_created_without_weights": True}
         del blob
+    else:
+        eng = make_engine(args.precision, args.num_scales, args.scale_gap, args.batch_frames, args.in_flight)
     frames = device_frames(eng)
     u8 = host_frames()
     if args.input == "host_u8":

@@ -37,6 +37,7 @@ class rtp_config(C.Structure):
         ("keep_blobs", C.c_int),
         ("calibrate_frames", C.c_int),
         ("calibrate_target", C.c_float),
+        ("defer_weights", C.c_int),
     ]
 
 

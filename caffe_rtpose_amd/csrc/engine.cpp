@@ -185,6 +185,7 @@ struct rtp_engine {
   float nms_threshold = 0.05f, inter_threshold = 0.05f, min_subset_score = 0.4f;
   int inter_min_above = 9, min_subset_cnt = 3;
   float start_scale = 1.f, scale_gap = 0.3f;
+  bool weights_pending = false;   // rtp_config.defer_weights: no weights yet (zero arena, no graphs): the net must not run until an import / peer copy
   bool calib_fell_back = false;   // rtp_calibrate_precision ended in RTP_PREC_F16X3 (its last resort)
   bool broken = false;   // a re-plan failed and the previous plan could not be restored: no contexts; every entry point fails, destroy works
   int N = 1;    // images per frame (num_scales)
@@ -1700,8 +1701,10 @@ int materialize_plan(rtp_engine* e, int nctx, bool capture) {
       if (s != hipSuccess) return fail(e, RTP_ENOMEM, "hipMalloc failed");
     }
   }
-  compute_wq_exp(e);
-  if ((rc = upload_all_weights(e))) return rc;
+  if (!e->weights_pending) {
+    compute_wq_exp(e);
+    if ((rc = upload_all_weights(e))) return rc;
+  }
   SYNC_GUARD;   // contexts (hipMemset of the arenas), the dry run's synchronisation, the graph captures
   e->ctx.resize(nctx);
   for (auto& c : e->ctx)
@@ -1768,6 +1771,24 @@ int busy_mark_stage0(rtp_engine* e, Ctx& cx) {
   if (!cx.ev_stage0) HIPCHK(e, hipEventCreate(&cx.ev_stage0));
   HIPCHK(e, hipEventRecord(cx.ev_stage0, cx.in_stream));
   cx.stage0_set = true;
+  return RTP_OK;
+}
+
+// rtp_config.defer_weights: entries that would run the net on an all-zero arena refuse
+int need_weights(rtp_engine* e) {
+  if (e->weights_pending) return fail(e, RTP_EINVAL, "this engine was created with defer_weights = 1 and has no weights yet: rtp_weight_blob_import or rtp_copy_weights_from first");
+  return RTP_OK;
+}
+// ... and once the weights are there, the launch graphs of every context are captured (what materialize_plan does for other engines)
+int weights_delivered(rtp_engine* e) {
+  if (!e->weights_pending) return RTP_OK;
+  e->weights_pending = false;
+  int rc;
+  if ((rc = invalidate_graphs(e))) return rc;
+  if (e->use_graph && !e->cfg.render)
+    for (auto& c : e->ctx)
+      for (int nf = e->B; nf >= 1; --nf)
+        if ((rc = capture_batch(e, c, nf, &c.gexec[nf]))) return rc;
   return RTP_OK;
 }
 
@@ -1857,6 +1878,7 @@ int rtp_config_default(rtp_config* cfg) {
   cfg->exec_mode = RTP_EXEC_GRAPH;
   cfg->calibrate_frames = 0;
   cfg->calibrate_target = 0.7e-3f;
+  cfg->defer_weights = 0;
   return RTP_OK;
 }
 
@@ -1978,7 +2000,14 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   // weights
   e->w_ref.resize(e->convs.size());
   e->b_ref.resize(e->convs.size());
-  if (!e->weights_path.empty()) {
+  e->weights_pending = cfg->defer_weights != 0;
+  if (e->weights_pending) {   // a receiving replica: sizes only (rtp_get_conv_weights / rtp_weight_blob_bytes need them), contents arrive with the blob
+    for (size_t i = 0; i < e->convs.size(); ++i) {
+      const ConvOp& c = e->convs[i];
+      e->w_ref[i].assign((size_t)c.cout * c.cin * c.k * c.k, 0.f);
+      e->b_ref[i].assign((size_t)c.cout, 0.f);
+    }
+  } else if (!e->weights_path.empty()) {
     std::vector<LayerWeights> lw;
     std::string werr;
     if (!read_caffemodel(e->weights_path, &lw, &werr)) return bail(fail(e, RTP_EIO, "%s", werr.c_str()));
@@ -2001,7 +2030,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   }
 
   e->nctx_full = (cfg->frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0);  // batches in flight (+1 being filled)
-  if ((rc = materialize_plan(e, e->nctx_full, true))) return bail(rc);
+  if ((rc = materialize_plan(e, e->nctx_full, !e->weights_pending))) return bail(rc);   // (a receiving replica captures when its weights arrive: wq_exp is baked into the graphs)
   if ((rc = build_prep_tables(e))) return bail(rc);
   // Load-time precision calibration (net.cpp:750-803 is where real weights arrive).  The default split set was chosen on synthetic
   // weights; weights that come from a FILE are checked by default (one synthetic frame: mixed vs F16X3, and the set is widened if the
@@ -2009,7 +2038,7 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   // calibrate_frames = -1 opts out; > 0 asks for that many frames (also for synthetic weights).
   int calib = cfg->calibrate_frames;
   if (calib == 0 && !e->weights_path.empty()) calib = 1;
-  if (calib > 0 && e->mode == RTP_PREC_MIXED) {
+  if (calib > 0 && e->mode == RTP_PREC_MIXED && !e->weights_pending) {
     float before = 0.f, after = 0.f;
     if ((rc = rtp_calibrate_precision(e, nullptr, calib, cfg->calibrate_target, nullptr, 0, &before, &after))) return bail(rc);
     if (cfg->calibrate_frames == 0 && (e->split_rules != (cfg->split_layers ? std::string(cfg->split_layers) : std::string(kDefaultSplit)) || e->mode != RTP_PREC_MIXED))
@@ -2084,6 +2113,7 @@ int rtp_submit_device(rtp_engine* e, const float* d_in, uint64_t tag) {
   if (!e || !d_in) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
@@ -2108,6 +2138,7 @@ int rtp_submit(rtp_engine* e, const float* h_in, uint64_t tag) {
   if (!e || !h_in) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
@@ -2135,6 +2166,7 @@ int rtp_submit_frame(rtp_engine* e, const unsigned char* bgr, int w, int h, uint
   if (!e || !bgr || w < 1 || h < 1) return RTP_EINVAL;
   int rc, ci, sj;
   if ((rc = use_device(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (e->prep_defer && (rc = pump(e, PUMP_POLL))) return rc;
   if ((rc = open_slot(e, &ci, &sj))) return rc;
   Ctx& cx = e->ctx[ci];
@@ -2274,6 +2306,7 @@ int rtp_forward_debug(rtp_engine* e, const float* h_in, float* lowres, float* re
   SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (!h_in) return RTP_EINVAL;
   Ctx& cx = e->ctx[0];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
@@ -2298,6 +2331,7 @@ int rtp_forward_heatmaps(rtp_engine* e, const float* h_in, float* lowres) {
   SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (!h_in || !lowres) return RTP_EINVAL;
   Ctx& cx = e->ctx[0];
   const size_t bytes = (size_t)e->N * 3 * e->cfg.net_h * e->cfg.net_w * sizeof(float);
@@ -2501,6 +2535,7 @@ int rtp_set_conv_weights(rtp_engine* e, int i, const float* w, const float* b) {
   if (!e || i < 0 || i >= (int)e->convs.size() || !w || !b) return RTP_EINVAL;
   int rc;
   if ((rc = need_idle(e))) return rc;
+  if ((rc = need_weights(e))) return rc;   // (a defer_weights engine takes its weights as ONE blob / peer copy, not layer by layer)
   e->w_ref[i].assign(w, w + e->w_ref[i].size());
   e->b_ref[i].assign(b, b + e->b_ref[i].size());
   HIPCHK(e, hipDeviceSynchronize());
@@ -3022,6 +3057,7 @@ int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes
   // the dozens of seconds a calibration can take)
   int rc;
   if ((rc = need_idle(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (e->mode == RTP_PREC_F16X3 && e->calib_fell_back) {   // an earlier calibration ended in the parity-grade mode: nothing is left to adjust
     if (err_before) *err_before = 0.f;
     if (err_after) *err_after = 0.f;
@@ -3212,6 +3248,7 @@ int rtp_weight_blob_export(rtp_engine* e, void* host, size_t capacity) {
   SYNC_GUARD;
   int rc;
   if ((rc = need_idle(e))) return rc;
+  if ((rc = need_weights(e))) return rc;
   if (!host || (long)capacity < rtp_weight_blob_bytes(e)) return fail(e, RTP_EINVAL, "weight blob needs %ld bytes", rtp_weight_blob_bytes(e));
   unsigned char* p = (unsigned char*)host;
   const uint64_t head[4] = {0x5254505742303031ull /* "RTPWB001" */, plan_hash(e), (uint64_t)e->convs.size(), (uint64_t)e->weights_bytes};
@@ -3244,7 +3281,7 @@ int rtp_weight_blob_import(rtp_engine* e, const void* host, size_t bytes) {
     memcpy(e->b_ref[i].data(), p, e->b_ref[i].size() * sizeof(float)); p += e->b_ref[i].size() * sizeof(float);
   }
   if (moved && (rc = invalidate_graphs(e))) return rc;  // ConvParams::wq_exp is baked into the captured graphs
-  return RTP_OK;
+  return weights_delivered(e);   // (defer_weights: the first weights of this engine — capture its graphs now)
 }
 // dst takes src's packed arena device-to-device (hipMemcpyPeer: xGMI between two GPUs of a node); both engines idle, same plan.
 int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src) {
@@ -3253,6 +3290,7 @@ int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src) {
   int rc;
   if ((rc = need_idle(dst))) return rc;
   if (!src->fifo.empty()) return fail(dst, RTP_EAGAIN, "rtp_copy_weights_from: the source engine has frames in flight");
+  if (src->weights_pending) return fail(dst, RTP_EINVAL, "rtp_copy_weights_from: the source engine has no weights itself (defer_weights)");
   if (plan_hash(dst) != plan_hash(src)) return fail(dst, RTP_EINVAL, "rtp_copy_weights_from: the engines have different plans");
   HIPCHK(dst, hipDeviceSynchronize());
   HIPCHK(dst, hipMemcpyPeer(dst->dweights, dst->cfg.device_id, src->dweights, src->cfg.device_id, dst->weights_bytes));
@@ -3264,7 +3302,7 @@ int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src) {
     dst->b_ref[i] = src->b_ref[i];
   }
   if (moved && (rc = invalidate_graphs(dst))) return rc;
-  return RTP_OK;
+  return weights_delivered(dst);
 }
 
 // Nothing may unwind through the C boundary: allocation failures while building a plan come back as codes.

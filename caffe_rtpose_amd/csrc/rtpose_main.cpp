@@ -347,27 +347,38 @@ void worker(int widx, int device, int* status) {
   rtp_engine* e = nullptr;
   const bool dry = F.dry_engine > 0;
   if (!dry && F.pin_workers && F.num_gpu > 1) pin_thread_near_device(widx, device);
+  // --share_weights: ONE read + pack of the model for N replicas.  Worker 0 loads (and, with --calibrate or a model file, calibrates);
+  // the others wait for it, are created WITHOUT weights (rtp_config.defer_weights) on worker 0's final split set and take its packed
+  // arena device to device before anybody submits a frame (worker 0's engine is idle until every worker is ready).
+  char src_rules[4096];
+  rtp_engine* src = nullptr;
+  if (!dry && F.share_weights && widx != 0) {
+    while (!(src = G.engine0.load()) && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if (!src) { *status = 1; return; }   // worker 0 failed and everybody is quitting: nothing was copied, nothing is counted
+    int prec = cfg.precision;
+    if (rtp_get_split_layers(src, src_rules, sizeof src_rules, &prec) != RTP_OK) { fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(src)); *status = 1; G.quit_threads = true; return; }
+    cfg.precision = prec;
+    cfg.split_layers = src_rules;
+    cfg.calibrate_frames = -1;
+    cfg.defer_weights = 1;
+  }
   if (!dry && rtp_engine_create(&cfg, &e) != RTP_OK) {
     fprintf(stderr, "GPU %d: %s\n", device, rtp_last_error(nullptr));
     *status = 1;
     G.quit_threads = true;
     return;
   }
-  if (!dry && F.share_weights) {  // worker 0 publishes its engine; the others take its packed arena before anybody submits a frame
+  if (!dry && F.share_weights) {
     if (widx == 0) G.engine0 = e;
     else {
-      while (!G.engine0.load() && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-      rtp_engine* src = G.engine0.load();
-      if (src) {   // (null: worker 0 failed and everybody is quitting — nothing was copied, nothing is counted)
-        if (rtp_copy_weights_from(e, src) != RTP_OK) {
-          fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(e));
-          *status = 1;
-          G.quit_threads = true;
-          rtp_engine_destroy(e);
-          return;
-        }
-        G.weights_shared++;
+      if (rtp_copy_weights_from(e, src) != RTP_OK) {
+        fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(e));
+        *status = 1;
+        G.quit_threads = true;
+        rtp_engine_destroy(e);
+        return;
       }
+      G.weights_shared++;
     }
   }
   int num_parts = F.model == "mpi" ? 15 : 18;

@@ -109,6 +109,14 @@ typedef struct rtp_config {
                             * stderr if the set had to change) and not at all for synthetic weights.           *
                             * -1: never (the split set stays exactly rtp_config.split_layers / the default).   */
   float calibrate_target;  /* max |mixed - f16x3| / max |map| the calibration accepts (<= 0: 0.7e-3)         */
+  int defer_weights;       /* 1: a RECEIVING replica of a one-time weight distribution: the engine is built      *
+                            * (plan, arena, contexts) but no weights are read, generated, packed or uploaded —    *
+                            * the arena stays zero and every entry that would run the net returns RTP_EINVAL      *
+                            * until rtp_weight_blob_import / rtp_copy_weights_from has delivered another          *
+                            * engine's packed weights (same plan: see there); the launch graphs are captured      *
+                            * then.  Saves the N-1 reads + packs of N replicas (rtpose.bin --share_weights,       *
+                            * bench.py --broadcast_weights).  No calibration runs on such an engine: create it    *
+                            * with the split set the source engine ended up with (rtp_get_split_layers).          */
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,

@@ -18,5 +18,6 @@ int rtp_collect(rtp_engine*, uint64_t*, float*, int*) { return RTP_ENODEV; }
 int rtp_collect_rendered(rtp_engine*, uint64_t*, float*, int*, unsigned char*) { return RTP_ENODEV; }
 int rtp_copy_weights_from(rtp_engine*, rtp_engine*) { return RTP_ENODEV; }
 int rtp_device_local_cpus(int, char*, size_t) { return 0; }
+int rtp_get_split_layers(const rtp_engine*, char*, size_t, int*) { return RTP_ENODEV; }
 const char* rtp_last_error(const rtp_engine*) { return "engine stub (sanitizer build of the host side): no device code in this binary"; }
 }

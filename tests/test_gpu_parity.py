@@ -853,7 +853,27 @@ def test_weight_blob_and_peer_copy_reproduce_the_source_engine():
     assert np.array_equal(ea.forward_heatmaps(x), before)       # refused = nothing written
     ew2.load_weight_blob(blob_w)                                # the same split set takes it
     assert np.array_equal(ew2.forward_heatmaps(x), ew.forward_heatmaps(x))
-    for e in (src, a, b, other, ew, ea, ew2):
+    # rtp_config.defer_weights (round 5): a RECEIVING replica is created without reading, generating, packing or uploading weights; the net cannot
+    # run until the blob / the peer copy arrives, and then it computes the source's maps bit for bit (graphs are captured at delivery)
+    recv = _engine(defer_weights=1, frames_in_flight=4, batch_frames=2, **{k: v for k, v in kw.items() if k not in ("frames_in_flight", "batch_frames")})
+    for call in (lambda: recv.forward_heatmaps(x), lambda: recv.submit(x, tag=1), lambda: recv.weight_blob(), lambda: recv.calibrate_precision(nframes=1),
+                 lambda: recv.set_conv_weights(0, *src.get_conv_weights(0)), lambda: b.copy_weights_from(recv)):
+        with pytest.raises(r.RtpError) as ei:
+            call()
+        assert ei.value.code == r.RTP_EINVAL
+    assert np.count_nonzero(recv.get_conv_weights(3)[0]) == 0          # sizes exist, contents do not
+    src2 = _engine(synthetic_seed=11, frames_in_flight=4, batch_frames=2, **{k: v for k, v in kw.items() if k not in ("frames_in_flight", "batch_frames")})
+    recv.load_weight_blob(src2.weight_blob())
+    assert np.array_equal(recv.forward_heatmaps(x), src2.forward_heatmaps(x)) and np.array_equal(recv.get_conv_weights(3)[0], src.get_conv_weights(3)[0])
+    for t in range(3):                                                  # a full batch and a trailing partial one through the graphs captured at delivery
+        recv.submit(x, tag=t)
+        src2.submit(x, tag=t)
+    got, ref3 = [recv.collect() for _ in range(3)], [src2.collect() for _ in range(3)]
+    assert all(g[0] == q[0] and g[1] == q[1] and np.array_equal(g[2], q[2]) for g, q in zip(got, ref3))
+    recv2 = _engine(defer_weights=1, **kw)
+    recv2.copy_weights_from(src)                                        # device to device
+    assert np.array_equal(recv2.forward_heatmaps(x), want)
+    for e in (src, a, b, other, ew, ea, ew2, recv, src2, recv2):
         e.close()
 
 
