@@ -29,10 +29,10 @@ deviation field through both post-processing chains; `cpu_baseline`: the
 OpenMP oracle port and torch-CPU conv2d over the same layers; `latency_ms.p50_single_frame`: one frame alone, commit -> joints on the
 host (rtpose.cpp:1430).
 
-On one GPU the line also carries `sub_results`: resident input, MPI 496x368 (BASELINE configs[4], with its own roofline and parity),
-3 scales (configs[2], the north-star target, with its own roofline and parity), single-pass fp16, the exact-f32 path, post-processing alone
-on analytic heat maps.  Every leg's headline scalar is repeated as `roofline.leg_*` and in the trailing `summary` object (the LAST key of
-the line), so a record that truncates the line or keeps only `roofline` still shows them.
+The printed line is COMPACT (compact_line(): <= 8 KB, one copy of the per-class rows); every leg's body — `sub_results` (resident input,
+MPI 496x368 = BASELINE configs[4] with its own roofline and parity, 3 scales = configs[2], single-pass fp16, exact-f32, post-processing alone
+on analytic heat maps), the parity explanations, the notes — goes to `bench_detail.json` next to this file (and under gpurun_out/ on the GPU
+box); the line's `summary` holds each leg's headline scalar.
 """
 import argparse
 import glob
@@ -444,6 +444,97 @@ def busy_account(spans):
                     "idle_frac = no stream of the engine had anything to run (rocprofv3's timeline of the same loop: profiles/, carries the tracer's overhead)"}
 
 
+LINE_LIMIT = 8192   # the driver keeps an 8 KB stdout tail: the ONE line must fit it whole
+
+
+def write_detail(out):
+    """Everything bench.py measured (sub-result bodies, per-leg rooflines, parity explanations, notes) as `bench_detail.json` next to
+    bench.py and, where the GPU box merges files back, under gpurun_out/.  Returns the paths written (relative to the repo)."""
+    paths = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if d != ROOT and not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                json.dump(out, f, indent=1)
+            paths.append(os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT))
+        except OSError:
+            pass
+    return paths
+
+
+def compact_line(out, detail_paths=()):
+    """The ONE JSON line of the bench contract, <= LINE_LIMIT bytes: the contract's scalar keys, `config` (workload string <= 300 chars),
+    ONE copy of the per-class rows (`roofline.classes` = {class: [launches per batch, us per launch, TFLOP/s]}), `cpu_baseline`, `parity`
+    and `summary` as scalars.  Everything else lives in bench_detail.json (write_detail)."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+
+    def rnd(v, n=4):
+        if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+            return v
+        v = float(v)
+        if not math.isfinite(v):
+            return None
+        return round(v, n) if abs(v) >= 1e-3 or v == 0 else float(f"{v:.3e}")
+
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "steps_requested", "warmup", "ms_per_step", "timed_region_s", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data")
+    line = {k: rnd(out[k], 6) for k in keep if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("precision", "input", "batch_frames", "frames_in_flight", "num_scales", "exec", "parallelism") if k in cfg}
+    line["config"]["workload"] = str(cfg.get("workload", ""))[:300]
+    roof = out.get("roofline") or {}
+    r_ = {k: rnd(roof.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_2q", "ms_per_launch", "launches_timed",
+                                           "flops_per_launch", "batch_ms_sum_of_launches", "idle_frac_kernel_stamps")
+          if k in roof}
+    if isinstance(roof.get("how"), str) and roof["how"].startswith("FALLBACK"):
+        r_["how"] = roof["how"][:200]
+    if g(roof, "solo", "frac") is not None:
+        r_["solo_frac"] = rnd(roof["solo"]["frac"])
+    byp = roof.get("by_mfma_passes") or {}
+    if byp:
+        r_["us_by_mfma_passes"] = {p: rnd(v["ms_per_launch"] * 1e3, 2) for p, v in byp.items()}
+    if roof.get("classes"):
+        r_["classes"] = {k: [v["steps_per_batch"], round(v["us_per_launch"], 1), round(v["tflops"])] for k, v in roof["classes"].items()}
+        r_["classes_columns"] = "launches per batch, us per launch, algorithmic TFLOP/s"
+    line["roofline"] = r_
+    line["conv_stack_frac"] = rnd(g(out, "conv_stack_whole_frame", "frac"))
+    lat = out.get("latency_ms") or {}
+    line["latency_ms"] = {k: rnd(lat[k], 3) for k in ("p50_single_frame", "p95_single_frame", "p50_pipelined", "p95_pipelined") if k in lat}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": rnd(cb.get("value"), 4), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": str(cb.get("sample", ""))[:200], "torch_conv_fps": rnd(cb.get("torch_conv_fps"), 3)}
+    par = out.get("parity")
+    if par:
+        line["parity"] = {k: rnd(par.get(k), 6) for k in ("verdict", "frames", "people_ref", "people_engine", "people_matched", "joints_ref", "joints_matched",
+                                                        "numeric_out_of_tol", "joints_structural", "structural_explained", "replay_identical",
+                                                        "max_dx_px", "max_dy_px", "max_dc", "map_max_err", "post_on_engine_maps_bit_exact") if k in par}
+        line["parity"]["verdict"] = str(par.get("verdict", ""))[:120]
+        if isinstance(par.get("structured"), dict):
+            line["parity"]["structured"] = str(par["structured"].get("verdict", ""))[:60]
+        if par.get("exact_modes"):
+            line["parity"]["exact_modes"] = par["exact_modes"]
+    for k in ("per_rank_frames_per_s", "comm_backend", "comm_note"):
+        if out.get(k) is not None:
+            line[k] = [rnd(v, 1) for v in out[k]] if isinstance(out[k], list) else str(out[k])[:200]
+    line["detail"] = list(detail_paths)
+    line["summary"] = {k: v for k, v in (out.get("summary") or {}).items() if not isinstance(v, (dict, list))}   # scalars only
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in (("roofline", "classes_columns"), ("cpu_baseline", "sample"), ("parity", "structured"), ("config", "workload")):   # never reached at today's sizes
+        if len(s) <= LINE_LIMIT:
+            break
+        line[drop[0]].pop(drop[1], None)
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_LIMIT:
+        line["summary"] = {k: v for k, v in line["summary"].items() if k in ("fps", "dominant_frac")}
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` with no launcher: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -681,10 +772,6 @@ def main():
                 classes, total = kernel_classes(plan, eng.conv_layers(), steps_t, eng.net_w, eng.net_h, nb * num_scales, peak)
                 roof["classes"] = classes
                 roof["batch_ms_sum_of_launches"] = total
-                for cls, row in classes.items():   # flat scalars too: a record that keeps only one level of `roofline` still shows them
-                    key = "cls_" + re.sub(r"[^a-z0-9]+", "_", cls.lower()).strip("_")
-                    roof[key + "_us"] = round(row["us_per_launch"], 2)
-                    roof[key + "_tflops"] = round(row["tflops"], 1)
         except Exception as ex:  # noqa: BLE001
             roof["classes_error"] = str(ex)
         return roof
@@ -829,13 +916,10 @@ def main():
                 "fp16_fps": rnd(g(sr, "precision_fp16_single_pass", "value")), "fp32_fps": rnd(g(sr, "precision_fp32", "value")),
                 "cpu_fps": rnd(g(out, "cpu_baseline", "value"), 3), "gpu_busy_frac": rnd(g(out, "gpu_busy", "busy_frac"), 4),
                 "parity": (g(out, "parity", "verdict") or "")[:40], "parity_replay_identical": g(out, "parity", "replay_identical"),
-                "parity_scales3": (g(sr, "scales3_gap0.15", "parity", "verdict") or "")[:40], "parity_mpi": (g(sr, "mpi_496x368", "parity", "verdict") or "")[:40],
-                "classes_us_tflops": {k: [round(v["us_per_launch"], 1), round(v["tflops"])] for k, v in (roof.get("classes") or {}).items()}}
-        for k, v in summ.items():
-            if k != "classes_us_tflops" and v is not None:
-                roof["leg_" + k] = v
+                "parity_scales3": (g(sr, "scales3_gap0.15", "parity", "verdict") or "")[:40], "parity_mpi": (g(sr, "mpi_496x368", "parity", "verdict") or "")[:40]}
         out["summary"] = summ
-        print(json.dumps(out))
+        detail_paths = write_detail(out)
+        print(compact_line(out, detail_paths))
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

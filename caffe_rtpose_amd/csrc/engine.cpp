@@ -2040,8 +2040,14 @@ static int engine_create_impl(const rtp_config* cfg, rtp_engine** out) {
   if (calib == 0 && !e->weights_path.empty()) calib = 1;
   if (calib > 0 && e->mode == RTP_PREC_MIXED && !e->weights_pending) {
     float before = 0.f, after = 0.f;
-    if ((rc = rtp_calibrate_precision(e, nullptr, calib, cfg->calibrate_target, nullptr, 0, &before, &after))) return bail(rc);
-    if (cfg->calibrate_frames == 0 && (e->split_rules != (cfg->split_layers ? std::string(cfg->split_layers) : std::string(kDefaultSplit)) || e->mode != RTP_PREC_MIXED))
+    rc = rtp_calibrate_precision(e, nullptr, calib, cfg->calibrate_target, nullptr, 0, &before, &after);
+    if (rc && (cfg->calibrate_frames > 0 || e->broken)) return bail(rc);   // asked for explicitly, or the engine lost its plan: a create failure
+    if (rc) {  // the UNREQUESTED default check could not run (reference maps zero / not finite on the synthetic frame, no memory for the trial
+               // plans next to N other processes, ...): rtp_calibrate_precision restored the plan it found — keep it and say so
+      fprintf(stderr, "rtpose-mi355x: the default precision check on the weights of %s could not run (%s); the engine keeps the default split set "
+                      "(rtp_config.calibrate_frames > 0 makes this an error, -1 skips the check)\n", e->weights_path.c_str(), e->err.c_str());
+      e->err.clear();
+    } else if (cfg->calibrate_frames == 0 && (e->split_rules != (cfg->split_layers ? std::string(cfg->split_layers) : std::string(kDefaultSplit)) || e->mode != RTP_PREC_MIXED))
       fprintf(stderr, "rtpose-mi355x: the default mixed-precision split set measured %.2e of the map maximum on the weights of %s (tolerance 1e-3, target %.1e): "
                       "now %s \"%s\" at %.2e (rtp_config.calibrate_frames = -1 keeps the default set)\n", before, e->weights_path.c_str(),
               cfg->calibrate_target > 0 ? cfg->calibrate_target : 0.7e-3f, e->mode == RTP_PREC_MIXED ? "mixed" : "f16x3", e->split_rules.c_str(), after);

@@ -56,3 +56,32 @@ def test_busy_account_is_the_union_of_the_spans():
     acc = b.busy_account(two)
     assert acc["busy_frac"] > 0.999 and 1.7 < acc["conv_stacks_concurrent_avg"] < 1.9
     assert b.busy_account(np.zeros((3, 3), np.float32)) is None
+
+
+def test_the_bench_line_is_compact_and_keeps_the_contract_keys():
+    """the driver parses ONE line out of an 8 KB stdout tail.  The round-5 record (27.7 KB as printed then) through
+    compact_line() must fit, parse, and still carry the contract's keys with one copy of the per-class rows."""
+    import json
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_style_steps20.json")))
+    line = b.compact_line(full, ["bench_detail.json"])
+    assert "\n" not in line and len(line) <= b.LINE_LIMIT
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity", "summary"):
+        assert k in d, k
+    assert abs(d["value"] - full["value"]) < 1e-5 and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert len(d["config"]["workload"]) <= 300 and "model" not in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    assert not [k for k in roof if k.startswith(("cls_", "leg_"))]
+    assert len(roof["classes"]) >= 8 and all(len(v) == 3 for v in roof["classes"].values())
+    assert "classes_us_tflops" not in d["summary"] and "sub_results" not in d
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("port", "reference")
+    assert d["parity"]["replay_identical"] is True and d["parity"]["numeric_out_of_tol"] == 0
+    # a pathological record (long strings everywhere) still fits
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "x" * 5000
+    fat["cpu_baseline"]["sample"] = "y" * 5000
+    fat["roofline"]["classes"] = {f"class {i} " + "z" * 40: v for i, v in enumerate(list(full["roofline"]["classes"].values()) * 4)}
+    assert len(b.compact_line(fat)) <= b.LINE_LIMIT
