@@ -235,6 +235,45 @@ def parity_report(eng, fr, model, num_scales, scale_gap, structured=True, start_
     return tot
 
 
+def exact_modes_table(make_engine, device_frames, measure, fr, model, num_scales, scale_gap, batch_frames, in_flight, mixed_row, modes=("f16x3", "fp32")):
+    """what an exact mode costs and buys in PEOPLE terms.  The SAME noise frames `fr` (oracle_frames()[1][1:]) through an
+    engine of each exact mode (RTP_PREC_F16X3 = every layer as three fp16 passes; RTP_PREC_FP32 = the reference's arithmetic) and through the
+    fp32 oracle chain: people / joints matched inside +-1 px / +-1e-3, structural differences, map error — next to the mode's pipelined
+    frames/s (resident inputs, the headline's batching).  `mixed_row` = the default mode's figures for the same frames."""
+    import numpy as np
+    import _oracle as orc
+    import _parity
+    mid, W, H, parts, max_peaks, _, _ = MODELS[model]
+    rows = {"mixed": mixed_row}
+    for mode in modes:
+        try:
+            e = make_engine(mode, num_scales, scale_gap, batch_frames, in_flight)
+            th = e.get_thresholds()
+            reps, map_err = [], 0.0
+            for x, ref, _ in fr:
+                norm = float(np.abs(ref).max())
+                res = orc.imresize(ref, W, H, 1.0, scale_gap)[0]
+                nr, jr = orc.connect(mid, res, orc.nms(res, parts, max_peaks, th["nms_threshold"]), max_peaks, W, H, 1280, 720, th)
+                e.submit(x, tag=1)
+                e.flush()
+                _, ne, je = e.collect()
+                rep = _parity.people_parity(je[:ne], jr[:nr], tol_px=1.0, tol_c=1e-3, c_norm=norm)
+                for k in ("structural", "out_of_tol", "_in_tol_max"):
+                    rep.pop(k, None)
+                reps.append(rep)
+                map_err = max(map_err, float(np.abs(e.forward_heatmaps(x) - ref).max() / norm))
+            tot = _parity.merge(reps)
+            f1 = device_frames(e)
+            m = measure(e, lambda i, tag: e.submit_device(f1[i % len(f1)], tag=tag), steps=50, warmup=10, in_flight=in_flight, min_seconds=1.0)
+            rows[mode] = {"fps_resident": round(m["fps"], 1), "people_ref": tot["people_ref"], "people_engine": tot["people_engine"], "people_matched": tot["people_matched"],
+                          "joints_ref": tot["joints_ref"], "joints_matched": tot["joints_matched"], "joints_structural": tot["joints_structural"],
+                          "numeric_out_of_tol": tot["numeric_out_of_tol"], "map_max_err": map_err}
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            rows[mode] = {"error": str(ex)}
+    return rows
+
+
 def structured_parity(eng, model, dev, scale_gap, start_scale=1.0):
     """Conv -> JSON parity on maps that LOOK like pose maps.  No trained weights exist offline, so the maps are
     planted: P = 1 / 5 / 20 stick figures as analytic low-res heat maps + PAFs (tests/_synth.people_lowres, values in [0, 1]).  The
@@ -516,11 +555,13 @@ def compact_line(out, detail_paths=()):
         line["parity"]["verdict"] = str(par.get("verdict", ""))[:120]
         if isinstance(par.get("structured"), dict):
             line["parity"]["structured"] = str(par["structured"].get("verdict", ""))[:60]
-        if par.get("exact_modes"):
+        if par.get("exact_modes"):   # {mode: [people matched, people of the fp32 reference, frames/s]} on the same noise frames
             line["parity"]["exact_modes"] = par["exact_modes"]
     for k in ("per_rank_frames_per_s", "comm_backend", "comm_note"):
         if out.get(k) is not None:
             line[k] = [rnd(v, 1) for v in out[k]] if isinstance(out[k], list) else str(out[k])[:200]
+    if isinstance(out.get("weight_broadcast"), dict):
+        line["weight_broadcast"] = {k: rnd(v, 3) for k, v in out["weight_broadcast"].items() if isinstance(v, (int, float, bool))}
     line["detail"] = list(detail_paths)
     line["summary"] = {k: v for k, v in (out.get("summary") or {}).items() if not isinstance(v, (dict, list))}   # scalars only
     s = json.dumps(line, separators=(",", ":"))
@@ -898,6 +939,16 @@ def main():
                     out["parity"] = parity_report(eng, orc_fr[1][1:], args.model, args.num_scales, args.scale_gap)
                 except Exception as ex:  # noqa: BLE001
                     out["parity"] = {"error": str(ex), "verdict": f"FAIL: {ex}"}
+                if args.precision == "mixed" and not args.no_sub_results and "error" not in out["parity"]:
+                    # the precision / throughput trade as one table: the same frames through the exact modes (bench_detail.json; a short form in the line)
+                    par = out["parity"]
+                    mixed_row = {"fps_resident": round(float(((out.get("sub_results") or {}).get("resident_input") or {}).get("value") or fps), 1),
+                                 **{k: par.get(k) for k in ("people_ref", "people_engine", "people_matched", "joints_ref", "joints_matched", "joints_structural",
+                                                            "numeric_out_of_tol")}, "map_max_err": par.get("map_max_err")}
+                    table = exact_modes_table(make_engine, device_frames, measure, orc_fr[1][1:], args.model, args.num_scales, args.scale_gap,
+                                              args.batch_frames, args.in_flight, mixed_row)
+                    out["exact_modes"] = table
+                    par["exact_modes"] = {k: [v.get("people_matched"), v.get("people_ref"), v.get("fps_resident")] for k, v in table.items() if "error" not in v}
         # A compact summary of every leg: the LAST key of the line (a truncated tail still shows it) and, as flat scalars, inside `roofline`
         # (records that keep `roofline` but not `sub_results` still show every leg's headline number).
         sr = out.get("sub_results") or {}

@@ -38,6 +38,14 @@ __device__ __forceinline__ void mma_fp8(const uint4& a0, const uint4& a1, const 
   b[0] = (int)b0.x; b[1] = (int)b0.y; b[2] = (int)b0.z; b[3] = (int)b0.w; b[4] = (int)b1.x; b[5] = (int)b1.y; b[6] = (int)b1.z; b[7] = (int)b1.w;
   c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
 }
+// the same instruction with other operand formats (cbsz / blgp: 0 = fp8 e4m3, 2 = fp6 e2m3, 4 = fp4 e2m1): experiments
+template <int FA, int FB>
+__device__ __forceinline__ void mma_q(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, floatx16& c, int sa, int sb) {
+  intx8 a, b;
+  a[0] = (int)a0.x; a[1] = (int)a0.y; a[2] = (int)a0.z; a[3] = (int)a0.w; a[4] = (int)a1.x; a[5] = (int)a1.y; a[6] = (int)a1.z; a[7] = (int)a1.w;
+  b[0] = (int)b0.x; b[1] = (int)b0.y; b[2] = (int)b0.z; b[3] = (int)b0.w; b[4] = (int)b1.x; b[5] = (int)b1.y; b[6] = (int)b1.z; b[7] = (int)b1.w;
+  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, FA, FB, 0, sa, 0, sb);
+}
 constexpr int Q_LO_EXP = 12, Q_HI_EXP = 2;             // q block: fp8(lo * 2^12), fp8(hi * 2^2)
 constexpr int Q_SA_LO = 127 - Q_LO_EXP, Q_SA_HI = 127 - Q_HI_EXP;
 // v_cvt_pk_fp8_f32 rounds to nearest even and keeps subnormals, but turns |x| > 464 into NaN: clamp first
@@ -73,7 +81,10 @@ __device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntil
 // One pixel x 16 channels of finished values (bias and ReLU applied) to every destination tensor of the problem: the value as T,
 // its rounding error as a lo block and / or as fp8 compensation operands where the destination carries them.
 template <typename T>
-__device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix, int c0, const float (&v)[16]) {
+__device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix, int c0, const float (&v)[16], int diag = 0) {
+#ifdef RTP_EXPERIMENTS
+  if (diag == 3) pix &= 15;   // timing only: every store instruction is issued, the dirty footprint is 16 pixels
+#endif
   constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
   const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
   T out[16];
@@ -87,6 +98,9 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix
       for (int u = 0; u < 16 / VEC; ++u) {
         uint4 pk;
         __builtin_memcpy(&pk, &out[u * VEC], 16);
+#ifdef RTP_EXPERIMENTS
+        if (diag == 4) { typedef unsigned u4v_t __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(__builtin_bit_cast(u4v_t, pk), (u4v_t*)dp + u); } else
+#endif
         ((uint4*)dp)[u] = pk;
       }
     } else {
@@ -150,6 +164,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
   static_assert(KSPLIT * BM * BN * 4 <= 160 * 1024, "partials fit in LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = (float*)smem;
+#ifdef RTP_EXPERIMENTS
+  if (P.diag == 2) { if (acc[0][0][0] == 12345.678f) red[threadIdx.x] = acc[TM - 1][TN - 1][15]; return; }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -161,19 +178,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
         const int col = wn0 + j * 32 + lrow;
         red[(kg * BM + row) * BN + col] = acc[i][j][q];
       }
-  __syncthreads();
-
   constexpr int CHUNKS = BN / 16;                 // 16-channel chunks per pixel row
   constexpr int ITEMS = BM * CHUNKS;
   constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
+  static_assert(256 % CHUNKS == 0, "a thread's items all belong to one 16-channel chunk");
+  // every item of a thread is the same 16-channel chunk (item = tid + 256 k, 256 % CHUNKS == 0): its bias is loaded ONCE, before the
+  // barrier, so that the global-load latency hides under the accumulator dump instead of opening every iteration of the item loop
+  const int chunk = (int)threadIdx.x % CHUNKS;
+  const int c0 = n0 + chunk * 16;
+  floatx4 bias4[4];
+  {
+    const floatx4* bsrc = (const floatx4*)(pr.bias + c0);  // bias is padded to CoutP (multiple of 64)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bias4[u] = bsrc[u];
+  }
+  __syncthreads();
+
   const int Mtot = P.H * P.Wp;
   const long img_pix0 = (long)img * P.img_pix + (long)P.halo * P.Wp;
   for (int item = threadIdx.x; item < ITEMS; item += 256) {
-    const int row = item / CHUNKS, chunk = item % CHUNKS;
+    const int row = item / CHUNKS;
     const int m = m0 + row;
     const int y = m / P.Wp;
     const int xp = m - y * P.Wp;
-    const int c0 = n0 + chunk * 16;
     if (m >= Mtot || xp < P.halo || xp >= P.halo + P.W || c0 >= pr.Cout) continue;
     float v[16];
     {
@@ -187,10 +214,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
         for (int u = 0; u < 4; ++u) { const floatx4 t = s2[u]; v[4 * u] += t[0]; v[4 * u + 1] += t[1]; v[4 * u + 2] += t[2]; v[4 * u + 3] += t[3]; }
       }
     }
-    const floatx4* bsrc = (const floatx4*)(pr.bias + c0);  // bias is padded to CoutP (multiple of 64)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const floatx4 bb = bsrc[u];
+      const floatx4 bb = bias4[u];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         float t = v[4 * u + e2] + bb[e2];
@@ -200,7 +226,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
     }
     const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
     const long pix = img_pix0 + m;
-    conv_store_pixel<T>(pr, pix, c0, v);
+#ifdef RTP_EXPERIMENTS
+    if (P.diag == 1 && v[3] != 12345.678f) continue;
+#endif
+    conv_store_pixel<T>(pr, pix, c0, v, P.diag);
     if (pr.out_nchw) {
       float* op = pr.out_nchw + (((long)img * pr.out_C + pr.out_coff + c0) * P.H + y) * P.W + (xp - P.halo);
       const long plane = (long)P.H * P.W;
@@ -221,6 +250,9 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
   static_assert(KSPLIT * BM * BN * 4 <= 160 * 1024, "partials fit in LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = (float*)smem;
+#ifdef RTP_EXPERIMENTS
+  if (P.diag == 2) { if (acc[0][0][0] == 12345.678f) red[threadIdx.x] = acc[TM - 1][TN - 1][15]; return; }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -231,13 +263,21 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
         const int col = wn0 + j * 32 + lrow;
         red[(kg * BM + row) * BN + col] = acc[i][j][q];
       }
-  __syncthreads();
   constexpr int CHUNKS = BN / 16, HALF = BM / 2, ITEMS = (HALF / 2) * CHUNKS;
+  static_assert(256 % CHUNKS == 0, "a thread's items all belong to one 16-channel chunk");
+  const int chunk = (int)threadIdx.x % CHUNKS;   // the same for every item of this thread: bias loaded once, under the accumulator dump
+  const int c0 = n0 + chunk * 16;
+  floatx4 bias4[4];
+  {
+    const floatx4* bsrc = (const floatx4*)(pr.bias + c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bias4[u] = bsrc[u];
+  }
+  __syncthreads();
   for (int item = threadIdx.x; item < ITEMS; item += 256) {
-    const int k = item / CHUNKS, chunk = item % CHUNKS;
+    const int k = item / CHUNKS;
     int x = x0 + 2 * k, pr_ = pair;
     if (x >= P.pool_wq) { x -= P.pool_wq; ++pr_; }  // the tile walked past the pitch (at most once, pitch > BM/2): these columns open the next row pair
-    const int c0 = n0 + chunk * 16;
     if (pr_ >= P.H / 2 || x >= P.W || c0 >= pr.Cout) continue;
     const long out_row = (long)img * P.pool_img_pix + (long)(pr_ + P.pool_halo) * P.pool_Wp + P.pool_halo;
     float v[16];
@@ -257,10 +297,9 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = (e == 0 || t[u] > v[u]) ? t[u] : v[u];
     }
-    const floatx4* bsrc = (const floatx4*)(pr.bias + c0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const floatx4 bb = bsrc[u];
+      const floatx4 bb = bias4[u];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         float t = v[4 * u + e2] + bb[e2];
@@ -268,6 +307,9 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
         v[4 * u + e2] = t;
       }
     }
+#ifdef RTP_EXPERIMENTS
+    if (P.diag == 1 && v[3] != 12345.678f) continue;
+#endif
     conv_store_pixel<T>(pr, out_row + (x >> 1), c0, v);
   }
 }

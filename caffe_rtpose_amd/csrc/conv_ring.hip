@@ -39,6 +39,20 @@ template <int CHB, int TM, bool ILV> __device__ __forceinline__ int ring_swz_a(i
   if constexpr (ILV && CHB == 256) return (row / TM) & 15;
   else return ring_swz<CHB>(row);
 }
+// ILV with 128-byte rows (the 3x3 trunk layers' fp8-compensated launches, the 185-channel stage-entry layers): one 256-byte bank row
+// holds a PAIR of strip rows, and the 16 lanes of a ds_read_b128 group read rows c + TM*l of one parity — a 3-bit key on the chunk
+// index can give them only 8 distinct slots (2-way conflict, SQ_LDS_BANK_CONFLICT 692k per conv3_2 launch against 89k for the
+// 256-byte dominant shape).  PAIR mode swizzles the 4-bit slot (parity, chunk) of the pair row R = row / 2 with (row / TM) & 15 —
+// a function of R for even TM — so the 16 lanes hit 16 distinct 16-byte slots; consecutive rows (the DMA side) stay conflict-free.
+template <int CHB, int TM, bool ILV> constexpr bool ring_pair_swz = ILV && CHB == 128 && (TM % 2) == 0;
+// byte offset of the 16-byte piece `cl` of strip row `row` inside a strip buffer
+template <int CHB, int TM, bool ILV> __device__ __forceinline__ int ring_a_offset(int row, int cl) {
+  if constexpr (ring_pair_swz<CHB, TM, ILV>) {
+    const int slot = (((row & 1) << 3) | cl) ^ ((row / TM) & 15);
+    return (row >> 1) * 256 + slot * 16;
+  } else
+    return row * CHB + ((cl ^ ring_swz_a<CHB, TM, ILV>(row)) * 16);
+}
 
 // every lane takes the value of the next higher lane (v_mov_b32_dpp wave_shl:1).  bound_ctrl: lane 63 (no source) gets 0 and
 // the destination is not tied to an "old" value (with old = src hipcc emitted a v_mov in front of every DPP move)
@@ -88,7 +102,7 @@ struct RingTraits {
   static_assert(G % KSPLIT == 0 && GPW >= 1, "k-groups split evenly");
   static_assert(B_INSTR % 4 == 0 && B_PW >= 1, "weight tile splits evenly over the waves");
   static_assert(KS == 3 || KS == 7, "strip reuse needs k > 1");
-  static_assert(SB >= 3 && (SB - 2) * B_PW + 2 * A_PW <= 63, "vmcnt is a 6-bit counter");
+  static_assert(SB >= 3 && (SB - 2) * B_PW + 2 * A_PW <= 63 && (SB - 1) * B_PW + A_PW <= 63, "vmcnt is a 6-bit counter");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -166,7 +180,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) {
 }
 
 // Pipeline (P = the tap whose fragments are being PREFETCHED, tap P-1 is being multiplied):
-//   prologue : DMA strip 0, strip 1, weight tiles 0..SB-1; wait tile 0; read fragments(0)
+//   prologue : DMA strip 0, weight tile 0, strip 1, weight tiles 1..SB-1; wait strip 0 + tile 0; read fragments(0)
 //   iteration P = 1..T-1:
 //       wait (counted) for tile P [+ its strip when s(P) == 0], lgkmcnt(0), s_barrier
 //         -> every wave has finished READING tile P-1 (its fragments sit in registers), so that
@@ -179,7 +193,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) {
 //  (1) tile P was issued SB-1 iterations ago.  Younger than it: the SB-2 tiles of iterations
 //      P-(SB-2)..P-1 and one strip for every such iteration u with s(u) == 0 (an iteration issues
 //      its strip BEFORE its weight tile); in the first strip only iterations u >= 1 exist.
-//  (2) at s == 0 (from the third strip on; strips 0 and 1 are the oldest DMAs of all) the strip of
+//  (2) at s == 0 (from the third strip on; strips 0 and 1 are older than weight tile 1) the strip of
 //      this filter row is needed; it was issued KS iterations ago: younger = KS tiles.
 // SB <= KS+1 keeps "at most one strip per window" and makes FIRST the only special case.
 template <int KS, int SB, bool FIRST, int B_PW, int A_PW>
@@ -293,6 +307,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       const int ar = wrap ? a - P.pool_wq : a;
       src_pix = (wrap ? 2 * P.Wp : 0) + (ar < P.W ? ar : P.W) + P.halo + PAD + sel * P.Wp;
     }
+    if constexpr (ring_pair_swz<CHB, TR::TM, ILV>) {  // LDS position (row, cphys) holds the logical piece (row', chunk') with the pair row's key (POOL is never ILV)
+      const int slot = (((row & 1) << 3) | cphys) ^ ((((row >> 1) * 2) / TR::TM) & 15);
+      a_voff[q] = (unsigned)(((row & ~1) + (slot >> 3)) * (int)pix_bytes + (slot & 7) * 16 - (q & 3) * 1024);
+    } else
     a_voff[q] = (unsigned)(src_pix * (int)pix_bytes + ((cphys ^ ring_swz_a<CHB, TR::TM, ILV>(row)) * 16) - (q & 3) * 1024);
   }
   const unsigned b_voff = (unsigned)(wave * B_PW * 1024 + lane * 16);
@@ -369,11 +387,16 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   if constexpr (SPEC) {
     int abuf = 0, st = 1, ist = 0;
     if (producer) {
+      // strip 0 and tile 0 FIRST: the first tap starts when these ~36-50 KiB have landed, with strip 1 and tiles 1..SB-1 still in
+      // flight behind them (every CU runs its prologue at the same time at ~11 B/clk/CU: each KiB less in front of the first MFMA
+      // is ~90 cycles of every workgroup's life).  Loads return in issue order, so the steady-state wait counts are unchanged:
+      // strip 1 is older than tile 1, which the first counted wait of the loop asks for.
       issue_a(0);
+      issue_b(0);
       issue_a(1);
 #pragma unroll
-      for (int i = 0; i < SB; ++i) issue_b(i);
-      wait_vmcnt<(SB - 1) * B_PW>();
+      for (int i = 1; i < SB; ++i) issue_b(i);
+      wait_vmcnt<(SB - 1) * B_PW + A_PW>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       auto pstep = [&](auto s_tag, auto first_tag) __attribute__((always_inline)) {
@@ -416,11 +439,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     // ---- consumers ----
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (P.clkprobe && tid == 0 && blockIdx.x == 0) P.clkprobe[2] = wall_clock64() - wall0;   // strip 0 + weight tile 0 have landed
     if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(3);
     // ILV: address of the 16-byte piece `cl` of this lane's row of A fragment i for tap s
     auto a_ilv = [&](int i, int s, int abuf_, int cl) __attribute__((always_inline)) {
       const int row = wm0 + TM * lrow + i + s;
-      return (const uint4*)(sA + abuf_ * TR::A_BYTES + row * CHB + ((cl ^ ring_swz_a<CHB, TM, true>(row)) * 16));
+      return (const uint4*)(sA + abuf_ * TR::A_BYTES + ring_a_offset<CHB, TM, true>(row, cl));
     };
     if constexpr (ILV) {
       const unsigned char* pb0 = pb_lane;
@@ -448,7 +472,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     //      every 16-byte fragment as one k-group (32x32x16 MFMA); an fp8 compensation tap (q chunk) uses fragments 2jj, 2jj+1
     //      together as the 8-register operand of one k-block of v_mfma_scale_f32_32x32x64_f8f6f4 (CANQ: the wave's share of a
     //      chunk is a whole number of 64-byte k-blocks). ----
-    constexpr bool CANQ = VAR == 100 && std::is_same<T, _Float16>::value && (GPW % 2 == 0);
+    constexpr bool QVAR = VAR >= 100 && VAR <= 103;  // 100 = production q kernel; 101..103 = timing-only experiments on it (wrong results)
+    constexpr bool CANQ = QVAR && std::is_same<T, _Float16>::value && (GPW % 2 == 0);
     constexpr int NKB = CANQ ? GPW / 2 : 1;
     constexpr int NRD_C = GPW * (TM + TN);
     const int sb_even = 127 - P.wq_exp, sb_odd = 127 - P.wq_exp - 11;  // E8M0 scales of W8 / W_lo8
@@ -480,6 +505,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       if constexpr (MQ && CANQ) {
         const int jj = m / (TM * TN), r = m % (TM * TN);
         const bool odd = ((kg * NKB + jj) & 1) != 0;
+        if constexpr (VAR == 101)       // timing only: the same registers read as fp4 (A) x fp6 e2m3 (B): the 2x-rate MFMA of an MX fp4 / fp6 correction
+          mma_q<4, 2>(fa[2 * jj][r / TN], fa[2 * jj + 1][r / TN], fb[2 * jj][r % TN], fb[2 * jj + 1][r % TN], acc[r / TN][r % TN], odd ? Q_SA_HI : Q_SA_LO, odd ? sb_odd : sb_even);
+        else if constexpr (VAR == 102) {  // timing only: ONE of the two corrections (the odd k-blocks' MFMAs are not issued)
+          if (!odd) mma_fp8(fa[2 * jj][r / TN], fa[2 * jj + 1][r / TN], fb[2 * jj][r % TN], fb[2 * jj + 1][r % TN], acc[r / TN][r % TN], Q_SA_LO, sb_even);
+        } else if constexpr (VAR == 103) {  // timing only: no correction MFMAs at all (the q bytes still travel)
+        } else
         mma_fp8(fa[2 * jj][r / TN], fa[2 * jj + 1][r / TN], fb[2 * jj][r % TN], fb[2 * jj + 1][r % TN], acc[r / TN][r % TN],
                 odd ? Q_SA_HI : Q_SA_LO, odd ? sb_odd : sb_even);
       } else if constexpr (VAR == 3) {  // timing only: accumulators forced into AGPRs (asm MFMA: no hazard padding by hipcc)
@@ -512,14 +543,14 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
 #pragma unroll
       for (int m = 0; m < NMMA_C; ++m) {
         mma_one_c(mq_tag, m);
-        if constexpr (VAR != 4 && (VAR != 100 || ILV) && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded over the first half of the tap
+        if constexpr (VAR != 4 && (!QVAR || ILV) && VAR != 11 && VAR != 16 && VAR != 17) {  // reads front-loaded over the first half of the tap
           constexpr int HALF = NMMA_C / 2 > 0 ? NMMA_C / 2 : 1;
           if (m < HALF) {
 #pragma unroll
             for (int rd = m * NRD_C / HALF; rd < (m + 1) * NRD_C / HALF; ++rd) read_one_c(s_tag, rd, pa, pb, aswz, abuf);
           }
           if constexpr (ILV && s != 0) { if (m == HALF - 1) read_boundary_c(s_tag, abuf); }
-        } else if constexpr (VAR == 4 || (VAR == 100 && !ILV)) {
+        } else if constexpr (VAR == 4 || (QVAR && !ILV)) {
 #pragma unroll
           for (int rd = m * NRD_C / NMMA_C; rd < (m + 1) * NRD_C / NMMA_C; ++rd) read_one_c(s_tag, rd, pa, pb, aswz, abuf);
           if constexpr (ILV && s != 0) { if (m == NMMA_C - 1) read_boundary_c(s_tag, abuf); }
@@ -578,6 +609,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     }
     wait_vmcnt<63>();
     __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
+    if (P.clkprobe && tid == 0 && blockIdx.x == 0) P.clkprobe[3] = wall_clock64() - wall0;   // K loop done
     if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0);
     else conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
     if (P.clkprobe && tid == 0 && blockIdx.x == 0) {  // shader-clock cycles vs 100 MHz wall clock over this workgroup's life
@@ -588,10 +620,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   }
   // ---- prologue ----------------------------------------------------------------------------
   issue_a(0);
+  issue_b(0);
   issue_a(1);
 #pragma unroll
-  for (int i = 0; i < SB; ++i) issue_b(i);
-  wait_vmcnt<(SB - 1) * B_PW>();  // strips 0,1 and tile 0 are the oldest
+  for (int i = 1; i < SB; ++i) issue_b(i);
+  wait_vmcnt<(SB - 1) * B_PW + A_PW>();  // strip 0 and tile 0 are the oldest
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   read_frags(0, 0, 0, fa, fb);
@@ -692,6 +725,13 @@ static hipError_t ring_launch_one(const ConvParams& P, int nprob, int N, hipStre
   }
   if (P.q_from > 0) {  // fp8-compensated layer: always the wave-specialised kernel, q instantiation
     if constexpr (std::is_same<T, _Float16>::value && ((CHB / 32) / KSPLIT) % 2 == 0) {
+#ifdef RTP_EXPERIMENTS  // timing-only variants of the q kernel (RTP_RING_VAR=101/102/103; wrong results)
+      if constexpr (BM == 128 && (BN == 64 || BN == 128)) {
+        if (P.variant == 101) return P.ilv ? ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 101, true>(P, nprob, N, stream) : ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 101>(P, nprob, N, stream);
+        if (P.variant == 102) return P.ilv ? ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 102, true>(P, nprob, N, stream) : ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 102>(P, nprob, N, stream);
+        if (P.variant == 103) return P.ilv ? ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 103, true>(P, nprob, N, stream) : ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 103>(P, nprob, N, stream);
+      }
+#endif
       if (P.ilv) return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100, true>(P, nprob, N, stream);
       return ring_launch_spec<T, BM, BN, WM, WN, KSPLIT, KS, CHB, SB_, 1, true, 100>(P, nprob, N, stream);
     } else

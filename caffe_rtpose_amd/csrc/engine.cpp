@@ -1065,6 +1065,8 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
     P.spec = (sp && sp[0] == '0') ? 0 : 1;  // wave-specialised ring kernels (default); 0 = every wave does both
     static const char* rv = RTP_EXP_ENV("RTP_RING_VAR");
     P.variant = rv ? atoi(rv) : 0;
+    static const char* ed = RTP_EXP_ENV("RTP_EPI_DIAG");   // experiments (timing only): 1 = epilogues do not store, 2 = no epilogue
+    P.diag = ed ? atoi(ed) : 0;
     static const char* il = RTP_EXP_ENV("RTP_RING_ILV");
     // interleaved A-fragment rows (conv_ring.hip ILV; bit-identical): default for the fp8-compensated launches, whose plain variant
     // spills 6 registers (44.6 vs 45.3 us on the dominant shape); the plain fp16 launches are faster without.  "1" = all, "0" = none
@@ -2960,19 +2962,21 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
   HIPCHK(e, hipEventSynchronize(cx.ev[1]));
   if (RTP_EXP_ENV("RTP_CLKPROBE")) {  // diagnostics: effective shader clock while this kernel runs back to back
     unsigned long long* d = nullptr;
-    HIPCHK(e, hipMalloc((void**)&d, 16));
-    HIPCHK(e, hipMemset(d, 0, 16));
+    HIPCHK(e, hipMalloc((void**)&d, 32));
+    HIPCHK(e, hipMemset(d, 0, 32));
     g_clkprobe = d;
     for (int i = 0; i < 20; ++i) if ((rc = launch_conv_step(e, cx, s, e->NI))) return rc;
     g_clkprobe = nullptr;
     HIPCHK(e, hipStreamSynchronize(cx.stream));
-    unsigned long long h[2] = {0, 0};
-    HIPCHK(e, hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(e, hipMemcpy(h, d, 32, hipMemcpyDeviceToHost));
     (void)hipFree(d);
     int khz = 100000;
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device_id);
     if (h[1]) fprintf(stderr, "clkprobe: %llu shader cycles in %llu wall ticks (%d kHz) -> %.0f MHz, workgroup 0 alive %.2f us\n", h[0], h[1], khz,
                       (double)h[0] / (double)h[1] * khz / 1e3, (double)h[1] / khz * 1e3);
+    if (h[1]) fprintf(stderr, "clkprobe: workgroup 0: first strip + tile landed at %.2f us, K loop done at %.2f us, epilogue done at %.2f us\n",
+                      (double)h[2] / khz * 1e3, (double)h[3] / khz * 1e3, (double)h[1] / khz * 1e3);
   }
   float ms = 0.f;
   HIPCHK(e, hipEventElapsedTime(&ms, cx.ev[0], cx.ev[1]));

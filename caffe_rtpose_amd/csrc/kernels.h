@@ -82,6 +82,7 @@ struct ConvParams {
   // geometry of the pooled (next) level
   int pool, pool_wq, pool_Wp, pool_halo;
   long pool_img_pix;
+  int diag;    // experiments build (env RTP_EPI_DIAG; timing only, wrong results): 1 = the epilogue computes but does not store, 2 = no epilogue at all
   unsigned long long* clkprobe;  // diagnostics: {shader clock cycles, wall clock ticks} of workgroup 0 (spec ring kernels)
 };
 
