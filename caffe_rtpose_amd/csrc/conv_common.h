@@ -78,20 +78,20 @@ __device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntil
   return b;
 }
 
-// One pixel x 16 channels of finished values (bias and ReLU applied) to every destination tensor of the problem: the value as T,
-// its rounding error as a lo block and / or as fp8 compensation operands where the destination carries them.
+// One pixel x 16 channels of finished values (bias and ReLU applied) to ONE destination tensor: the value as T, its rounding error as a
+// lo block and / or as fp8 compensation operands where the destination carries them.  `dd` is a by-value copy of the descriptor: the
+// epilogues load destination 0's once per thread, in front of their barrier (one batch of scalar loads whose latency hides under the
+// accumulator dump), where the per-item walk through the kernel-argument table cost ~8 dependent scalar loads per item
+// (~0.7 us per item iteration: 1.6 of the 3.5 us epilogue of the dominant launch, profiles/r06_experiments.txt).
 template <typename T>
-__device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix, int c0, const float (&v)[16], int diag = 0) {
+__device__ __forceinline__ void conv_store_dst(const ConvDst dd, int Cout, long pix, int c0, const float (&v)[16], const T (&out)[16], int diag = 0) {
+  constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
+  const int nvalid = (Cout - c0) < 16 ? (Cout - c0) : 16;
 #ifdef RTP_EXPERIMENTS
   if (diag == 3) pix &= 15;   // timing only: every store instruction is issued, the dirty footprint is 16 pixels
 #endif
-  constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
-  const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
-  T out[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) out[u] = (T)v[u];
-  for (int d = 0; d < pr.ndst; ++d) {
-    T* dp = (T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].coff + c0;
+  {
+    T* dp = (T*)dd.base + pix * dd.cstride + dd.coff + c0;
     const bool vec_ok = nvalid == 16 && (((size_t)dp) & 15) == 0;
     if (vec_ok) {
 #pragma unroll
@@ -106,11 +106,11 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix
     } else {
       for (int u = 0; u < nvalid; ++u) dp[u] = out[u];
     }
-    if (pr.dst[d].lo_off) {  // split-precision consumer: the rounding error of the stored value, as a second T
+    if (dd.lo_off) {  // split-precision consumer: the rounding error of the stored value, as a second T
       T lo[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) lo[u] = (T)(v[u] - (float)out[u]);
-      T* lp = dp + pr.dst[d].lo_off;
+      T* lp = dp + dd.lo_off;
       if (vec_ok && (((size_t)lp) & 15) == 0) {
 #pragma unroll
         for (int u = 0; u < 16 / VEC; ++u) {
@@ -123,9 +123,9 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix
       }
     }
     if constexpr (sizeof(T) == 2) {
-      if (pr.dst[d].q_off) {  // fp8 compensation operands for a consumer that runs the fp8 passes
-        const int ch = pr.dst[d].coff + c0;
-        unsigned char* qrow = (unsigned char*)((T*)pr.dst[d].base + pix * pr.dst[d].cstride + pr.dst[d].q_off);
+      if (dd.q_off) {  // fp8 compensation operands for a consumer that runs the fp8 passes
+        const int ch = dd.coff + c0;
+        unsigned char* qrow = (unsigned char*)((T*)dd.base + pix * dd.cstride + dd.q_off);
         float lof[16], hif[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) { hif[u] = (float)out[u]; lof[u] = (v[u] - hif[u]) * (float)(1 << Q_LO_EXP); hif[u] *= (float)(1 << Q_HI_EXP); }
@@ -149,6 +149,17 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, long pix
       }
     }
   }
+}
+
+// ... to every destination tensor of the problem: destination 0 from the caller's register copy `d0`, any further one (concat slices:
+// conv4_4_CPM, the branch tails) through the kernel-argument table.
+template <typename T>
+__device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, const ConvDst d0, int ndst, int Cout, long pix, int c0, const float (&v)[16], int diag = 0) {
+  T out[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) out[u] = (T)v[u];
+  conv_store_dst<T>(d0, Cout, pix, c0, v, out, diag);
+  for (int d = 1; d < ndst; ++d) conv_store_dst<T>(pr.dst[d], Cout, pix, c0, v, out, diag);
 }
 
 // Epilogue: every wave dumps its fp32 accumulators into LDS as [kg][row][col] (the staging LDS is
@@ -192,6 +203,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
 #pragma unroll
     for (int u = 0; u < 4; ++u) bias4[u] = bsrc[u];
   }
+  const ConvDst d0 = pr.dst[0];          // destination 0's descriptor, the counts and the flags: scalar loads in ONE batch, before the barrier
+  const int ndst = pr.ndst, Cout = pr.Cout, relu = P.relu;
+  float* const out_nchw = pr.out_nchw;
   __syncthreads();
 
   const int Mtot = P.H * P.Wp;
@@ -201,7 +215,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
     const int m = m0 + row;
     const int y = m / P.Wp;
     const int xp = m - y * P.Wp;
-    if (m >= Mtot || xp < P.halo || xp >= P.halo + P.W || c0 >= pr.Cout) continue;
+    if (m >= Mtot || xp < P.halo || xp >= P.halo + P.W || c0 >= Cout) continue;
     float v[16];
     {
       const floatx4* src = (const floatx4*)(red + row * BN + chunk * 16);
@@ -220,18 +234,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         float t = v[4 * u + e2] + bb[e2];
-        if (P.relu) t = t > 0.f ? t : 0.f;
+        if (relu) t = t > 0.f ? t : 0.f;
         v[4 * u + e2] = t;
       }
     }
-    const int nvalid = (pr.Cout - c0) < 16 ? (pr.Cout - c0) : 16;
+    const int nvalid = (Cout - c0) < 16 ? (Cout - c0) : 16;
     const long pix = img_pix0 + m;
 #ifdef RTP_EXPERIMENTS
     if (P.diag == 1 && v[3] != 12345.678f) continue;
 #endif
-    conv_store_pixel<T>(pr, pix, c0, v, P.diag);
-    if (pr.out_nchw) {
-      float* op = pr.out_nchw + (((long)img * pr.out_C + pr.out_coff + c0) * P.H + y) * P.W + (xp - P.halo);
+    conv_store_pixel<T>(pr, d0, ndst, Cout, pix, c0, v, P.diag);
+    if (out_nchw) {
+      float* op = out_nchw + (((long)img * pr.out_C + pr.out_coff + c0) * P.H + y) * P.W + (xp - P.halo);
       const long plane = (long)P.H * P.W;
       for (int u = 0; u < nvalid; ++u) op[u * plane] = v[u];
     }
@@ -273,12 +287,14 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
 #pragma unroll
     for (int u = 0; u < 4; ++u) bias4[u] = bsrc[u];
   }
+  const ConvDst d0 = pr.dst[0];
+  const int ndst = pr.ndst, Cout = pr.Cout, relu = P.relu;
   __syncthreads();
   for (int item = threadIdx.x; item < ITEMS; item += 256) {
     const int k = item / CHUNKS;
     int x = x0 + 2 * k, pr_ = pair;
     if (x >= P.pool_wq) { x -= P.pool_wq; ++pr_; }  // the tile walked past the pitch (at most once, pitch > BM/2): these columns open the next row pair
-    if (pr_ >= P.H / 2 || x >= P.W || c0 >= pr.Cout) continue;
+    if (pr_ >= P.H / 2 || x >= P.W || c0 >= Cout) continue;
     const long out_row = (long)img * P.pool_img_pix + (long)(pr_ + P.pool_halo) * P.pool_Wp + P.pool_halo;
     float v[16];
 #pragma unroll
@@ -303,14 +319,14 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         float t = v[4 * u + e2] + bb[e2];
-        if (P.relu) t = t > 0.f ? t : 0.f;
+        if (relu) t = t > 0.f ? t : 0.f;
         v[4 * u + e2] = t;
       }
     }
 #ifdef RTP_EXPERIMENTS
     if (P.diag == 1 && v[3] != 12345.678f) continue;
 #endif
-    conv_store_pixel<T>(pr, out_row + (x >> 1), c0, v);
+    conv_store_pixel<T>(pr, d0, ndst, Cout, out_row + (x >> 1), c0, v);
   }
 }
 
