@@ -162,6 +162,21 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, const Co
   for (int d = 1; d < ndst; ++d) conv_store_dst<T>(pr.dst[d], Cout, pix, c0, v, out, diag);
 }
 
+// Position of (row, col) inside the epilogues' fp32 staging image (BN floats per row).  The 16-byte group index of a row is XORed with
+// f(row) = ((row >> RS) & 3) | (bit HB of row) << 3:
+//   * the dump: one ds_write_b32 puts lanes 0..31 on 32 consecutive columns of one row and lanes 32..63 on the same columns of the row whose
+//     bit HB differs (MFMA accumulator layout) — with BN a multiple of 64 both halves would hit the same 32 banks; the flipped bit 3 of the
+//     group index sends the second half to the other 32;
+//   * the item loop: the 16 lanes of a ds_read_b128 phase read the same 16-byte group of 4 consecutive rows (x 4 chunks): 4-way conflict
+//     without the row's low bits in the key, none with them (BN = 64; 2-way remains for BN = 128, where chunks c and c + 4 share banks).
+template <int BN, int HB, int RS = 0>
+__device__ __forceinline__ int red_key(int row) {
+  if constexpr (BN >= 64) return ((row >> RS) & 3) | (((row >> HB) & 1) << 3);
+  else return 0;
+}
+template <int BN, int HB, int RS = 0>
+__device__ __forceinline__ int red_pos(int row, int col) { return row * BN + ((((col >> 2) ^ red_key<BN, HB, RS>(row)) << 2) | (col & 3)); }
+
 // Epilogue: every wave dumps its fp32 accumulators into LDS as [kg][row][col] (the staging LDS is
 // dead: callers barrier first), then ALL 256 threads own (pixel row, 16-channel chunk) items: sum
 // the KSPLIT partials, add bias, ReLU, convert, and store 16 channels with 16-byte vector stores
@@ -169,30 +184,35 @@ __device__ __forceinline__ void conv_store_pixel(const ConvProblem& pr, const Co
 // per item instead of one per element, no idle waves.
 // acc layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // ILV: fragment i of a wave covers the pixels TM*r + i instead of 32*i + r (conv_ring.hip, interleaved fragment rows).
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN, bool ILV = false>
+// NT = threads that run the item loop (512 in the wave-specialised ring kernels: the four DMA waves have nothing left to load and take
+// half of the items; they call with dump = false, their accumulators are not the tile's).
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN, bool ILV = false, int NT = 256>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
-                                              int kg, int wrem, int wm0, int wn0, int lane, int img, int m0, int n0) {
+                                              int kg, int wrem, int wm0, int wn0, int lane, int img, int m0, int n0, bool dump = true) {
   static_assert(KSPLIT * BM * BN * 4 <= 160 * 1024, "partials fit in LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = (float*)smem;
+  constexpr int HB = ILV ? (TM == 4 ? 4 : TM == 2 ? 3 : 2) : 2;   // the row bit that lane half 1 sets in the accumulator layout
 #ifdef RTP_EXPERIMENTS
   if (P.diag == 2) { if (acc[0][0][0] == 12345.678f) red[threadIdx.x] = acc[TM - 1][TN - 1][15]; return; }
 #endif
+  if (dump) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int r32 = (q & 3) + 8 * (q >> 2) + 4 * lhalf;
-        const int row = ILV ? wm0 + TM * r32 + i : wm0 + i * 32 + r32;
-        const int col = wn0 + j * 32 + lrow;
-        red[(kg * BM + row) * BN + col] = acc[i][j][q];
-      }
+        for (int q = 0; q < 16; ++q) {
+          const int r32 = (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+          const int row = ILV ? wm0 + TM * r32 + i : wm0 + i * 32 + r32;
+          const int col = wn0 + j * 32 + lrow;
+          red[kg * BM * BN + red_pos<BN, HB>(row, col)] = acc[i][j][q];
+        }
+  }
   constexpr int CHUNKS = BN / 16;                 // 16-channel chunks per pixel row
   constexpr int ITEMS = BM * CHUNKS;
   constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte store
-  static_assert(256 % CHUNKS == 0, "a thread's items all belong to one 16-channel chunk");
+  static_assert(256 % CHUNKS == 0 && NT % 256 == 0, "a thread's items all belong to one 16-channel chunk");
   // every item of a thread is the same 16-channel chunk (item = tid + 256 k, 256 % CHUNKS == 0): its bias is loaded ONCE, before the
   // barrier, so that the global-load latency hides under the accumulator dump instead of opening every iteration of the item loop
   const int chunk = (int)threadIdx.x % CHUNKS;
@@ -210,7 +230,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
 
   const int Mtot = P.H * P.Wp;
   const long img_pix0 = (long)img * P.img_pix + (long)P.halo * P.Wp;
-  for (int item = threadIdx.x; item < ITEMS; item += 256) {
+  for (int item = threadIdx.x; item < ITEMS; item += NT) {
     const int row = item / CHUNKS;
     const int m = m0 + row;
     const int y = m / P.Wp;
@@ -218,14 +238,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
     if (m >= Mtot || xp < P.halo || xp >= P.halo + P.W || c0 >= Cout) continue;
     float v[16];
     {
-      const floatx4* src = (const floatx4*)(red + row * BN + chunk * 16);
+      const int key = red_key<BN, HB>(row);
+      const float* src = red + row * BN;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const floatx4 t = src[u]; v[4 * u] = t[0]; v[4 * u + 1] = t[1]; v[4 * u + 2] = t[2]; v[4 * u + 3] = t[3]; }
+      for (int u = 0; u < 4; ++u) { const floatx4 t = *(const floatx4*)(src + (((chunk * 4 + u) ^ key) << 2)); v[4 * u] = t[0]; v[4 * u + 1] = t[1]; v[4 * u + 2] = t[2]; v[4 * u + 3] = t[3]; }
 #pragma unroll
       for (int k2 = 1; k2 < KSPLIT; ++k2) {
-        const floatx4* s2 = (const floatx4*)(red + (k2 * BM + row) * BN + chunk * 16);
+        const float* s2 = red + (k2 * BM + row) * BN;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const floatx4 t = s2[u]; v[4 * u] += t[0]; v[4 * u + 1] += t[1]; v[4 * u + 2] += t[2]; v[4 * u + 3] += t[3]; }
+        for (int u = 0; u < 4; ++u) { const floatx4 t = *(const floatx4*)(s2 + (((chunk * 4 + u) ^ key) << 2)); v[4 * u] += t[0]; v[4 * u + 1] += t[1]; v[4 * u + 2] += t[2]; v[4 * u + 3] += t[3]; }
       }
     }
 #pragma unroll
@@ -258,27 +279,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
 // the fp32 sums (after the KSPLIT reduction): bias add, ReLU and the conversions to T / lo / fp8 are monotone, so
 // max-then-convert stores exactly the bytes convert-then-pool stores (the stand-alone pooling kernel keeps the element with
 // the largest (hi, lo) pair, which is the element with the largest fp32 value).  Only the POOLED tensor is written.
-template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN>
+template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int TM, int TN, int NT = 256>
 __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const ConvProblem& pr, floatx16 (&acc)[TM][TN], unsigned char* smem,
-                                                   int kg, int wm0, int wn0, int lane, int img, int pair, int x0, int n0) {
+                                                   int kg, int wm0, int wn0, int lane, int img, int pair, int x0, int n0, bool dump = true) {
   static_assert(KSPLIT * BM * BN * 4 <= 160 * 1024, "partials fit in LDS");
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = (float*)smem;
 #ifdef RTP_EXPERIMENTS
   if (P.diag == 2) { if (acc[0][0][0] == 12345.678f) red[threadIdx.x] = acc[TM - 1][TN - 1][15]; return; }
 #endif
+  if (dump) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
-        const int col = wn0 + j * 32 + lrow;
-        red[(kg * BM + row) * BN + col] = acc[i][j][q];
-      }
+        for (int q = 0; q < 16; ++q) {
+          const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+          const int col = wn0 + j * 32 + lrow;
+          red[kg * BM * BN + red_pos<BN, 2, 1>(row, col)] = acc[i][j][q];   // (RS = 1: the item loop's lanes walk EVEN or ODD rows)
+        }
+  }
   constexpr int CHUNKS = BN / 16, HALF = BM / 2, ITEMS = (HALF / 2) * CHUNKS;
-  static_assert(256 % CHUNKS == 0, "a thread's items all belong to one 16-channel chunk");
+  static_assert(256 % CHUNKS == 0 && NT % 256 == 0, "a thread's items all belong to one 16-channel chunk");
   const int chunk = (int)threadIdx.x % CHUNKS;   // the same for every item of this thread: bias loaded once, under the accumulator dump
   const int c0 = n0 + chunk * 16;
   floatx4 bias4[4];
@@ -290,7 +313,7 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
   const ConvDst d0 = pr.dst[0];
   const int ndst = pr.ndst, Cout = pr.Cout, relu = P.relu;
   __syncthreads();
-  for (int item = threadIdx.x; item < ITEMS; item += 256) {
+  for (int item = threadIdx.x; item < ITEMS; item += NT) {
     const int k = item / CHUNKS;
     int x = x0 + 2 * k, pr_ = pair;
     if (x >= P.pool_wq) { x -= P.pool_wq; ++pr_; }  // the tile walked past the pitch (at most once, pitch > BM/2): these columns open the next row pair
@@ -301,14 +324,15 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvParams& P, const Co
     for (int e = 0; e < 4; ++e) {  // (0,0) (0,1) (1,0) (1,1)
       const int row = (e >> 1) * HALF + 2 * k + (e & 1);
       float t[16];
-      const floatx4* src = (const floatx4*)(red + row * BN + chunk * 16);
+      const int key = red_key<BN, 2, 1>(row);
+      const float* src = red + row * BN;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const floatx4 w = src[u]; t[4 * u] = w[0]; t[4 * u + 1] = w[1]; t[4 * u + 2] = w[2]; t[4 * u + 3] = w[3]; }
+      for (int u = 0; u < 4; ++u) { const floatx4 w = *(const floatx4*)(src + (((chunk * 4 + u) ^ key) << 2)); t[4 * u] = w[0]; t[4 * u + 1] = w[1]; t[4 * u + 2] = w[2]; t[4 * u + 3] = w[3]; }
 #pragma unroll
       for (int k2 = 1; k2 < KSPLIT; ++k2) {
-        const floatx4* s2 = (const floatx4*)(red + (k2 * BM + row) * BN + chunk * 16);
+        const float* s2 = red + (k2 * BM + row) * BN;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const floatx4 w = s2[u]; t[4 * u] += w[0]; t[4 * u + 1] += w[1]; t[4 * u + 2] += w[2]; t[4 * u + 3] += w[3]; }
+        for (int u = 0; u < 4; ++u) { const floatx4 w = *(const floatx4*)(s2 + (((chunk * 4 + u) ^ key) << 2)); t[4 * u] += w[0]; t[4 * u + 1] += w[1]; t[4 * u + 2] += w[2]; t[4 * u + 3] += w[3]; }
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = (e == 0 || t[u] > v[u]) ? t[u] : v[u];

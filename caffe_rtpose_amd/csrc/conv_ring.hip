@@ -434,7 +434,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       }
       wait_vmcnt<0>();  // the dummy tail DMAs have landed before LDS is reused by the epilogue
       __builtin_amdgcn_s_barrier();
-      return;           // the consumers' later barriers count live waves only
+      // the DMA waves stay for the epilogue: they take half of the (pixel, 16-channel chunk) items of the staged tile (dump = false)
+      if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN, 512>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0, false);
+      else conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV, 512>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0, false);
+      return;
     }
     // ---- consumers ----
     __builtin_amdgcn_s_barrier();
@@ -610,8 +613,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
     wait_vmcnt<63>();
     __builtin_amdgcn_s_barrier();  // pairs with the producers' drain barrier
     if (P.clkprobe && tid == 0 && blockIdx.x == 0) P.clkprobe[3] = wall_clock64() - wall0;   // K loop done
-    if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0);
-    else conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
+    if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN, 512>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0);
+    else conv_epilogue<T, BM, BN, WM, WN, KSPLIT, TM, TN, ILV, 512>(P, pr, acc, smem, kg, wrem, wm0, wn0, lane, img, m0, n0);
     if (P.clkprobe && tid == 0 && blockIdx.x == 0) {  // shader-clock cycles vs 100 MHz wall clock over this workgroup's life
       P.clkprobe[0] = clock64() - clk0;
       P.clkprobe[1] = wall_clock64() - wall0;
