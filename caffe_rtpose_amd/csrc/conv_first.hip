@@ -23,6 +23,7 @@ constexpr int FIRST_ZERO_SLOT = 8;  // halves
 }
 
 __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams Q) {
+  const KStamp kstamp_(Q.stamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_first[];
   _Float16* tile = (_Float16*)smem_first;
   const int W = Q.g.W, H = Q.g.H, TW = W + 2, TW3 = TW * 3;

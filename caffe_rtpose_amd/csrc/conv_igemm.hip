@@ -56,6 +56,7 @@ struct ConvTraits {
 
 template <typename T, int BM, int BN, int WM, int WN, int KSPLIT, int KS, int ROWB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams P) {
+  const KStamp kstamp_(P.stamp);
   using TR = ConvTraits<T, BM, BN, WM, WN, KSPLIT, KS, ROWB>;
   constexpr int NT = TR::NT, STR = TR::STR, VPR = TR::VPR;
   constexpr int A_IT = TR::A_IT, B_IT = TR::B_IT, G = TR::G, TM = TR::TM, TN = TR::TN;

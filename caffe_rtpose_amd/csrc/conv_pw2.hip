@@ -59,6 +59,7 @@ __device__ __forceinline__ void pw_stash(const V& reg, unsigned char* sW, int ti
 }
 
 __global__ __launch_bounds__(256) void conv_pw2_kernel(Pw2Params Q) {
+  const KStamp kstamp_(Q.P2.stamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sXh = smem;
   unsigned char* sXl = smem + PW_X;

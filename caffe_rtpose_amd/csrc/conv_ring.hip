@@ -251,6 +251,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
   unsigned char* sA = smem;
   unsigned char* sB = smem + 2 * TR::A_BYTES;
 
+  const KStamp kstamp_(P.stamp);
   const BlockCoord bc = decode_block(P, P.CoutP / BN, P.tiles_per_img * P.nimg);
   const ConvProblem& pr = P.prob[bc.prob];
   const int tid = threadIdx.x;

@@ -171,6 +171,8 @@ struct Ctx {
   bool stage0_set = false;
   bool graph_run = false;                 // the batch in flight was ONE graph replay incl. post-processing (collect waits on gev[1])
   bool graph_conv = false;                // the conv stack was a replay, the post-processing chains were launched eagerly
+  unsigned long long* stamps = nullptr;   // rtp_stamp_probe: STAMP_SLOTS x {~first workgroup start, last workgroup end} of this context's launches (kernels.h KStamp)
+  bool stamps_dirty = false;
 };
 
 }  // namespace
@@ -227,6 +229,10 @@ struct rtp_engine {
   bool busy_probe = false;
   hipEvent_t busy_base = nullptr;
   std::vector<float> busy_spans;          // [n][3]: kind (0 conv stream, 1 post chain), start ms, end ms
+  // rtp_stamp_probe: device-side residency stamps of every kernel of the per-frame path (no profiler, no events)
+  bool stamp_probe = false;
+  unsigned long long stamp_base = 0;      // wall-clock ticks (100 MHz) of the first harvested start
+  std::vector<float> stamp_spans;         // [n][3]: slot id (see stamp_slot), start us, end us relative to stamp_base
   bool time_all = false;                  // rtp_kernel_timing(3): an event pair around EVERY step of a full batch, not only the dominant class
   std::vector<double> step_ms;            // per plan step: event-timed milliseconds / launches of the timing pass (rtp_kernel_timing_steps)
   std::vector<long> step_n;
@@ -998,6 +1004,32 @@ int upload_all_weights(rtp_engine* e) {
 }
 
 // ---- launches -------------------------------------------------------------------------------
+// Residency-stamp slots of one batch context: [0, 64) plan steps (conv stack), 64 + 8 j + {0 strip, 1 write, 2 pairs, 3 match, 4 assemble}
+// = frame j's post-processing chain, 200 + 2 j + {0 warp, 1 area/pad} = frame j's device pre-processing.
+constexpr int STAMP_SLOTS = 256;
+unsigned long long* stamp_slot(const rtp_engine* e, const Ctx& cx, int idx) {
+  return (e->stamp_probe && cx.stamps && idx >= 0 && idx < STAMP_SLOTS) ? cx.stamps + 2 * (size_t)idx : nullptr;
+}
+// the stamps of the batch that last ran on `cx` (complete: the context is idle) -> e->stamp_spans; slots zeroed for the next batch
+int stamp_harvest(rtp_engine* e, Ctx& cx) {
+  if (!cx.stamps || !cx.stamps_dirty) return RTP_OK;
+  std::vector<unsigned long long> h(2 * STAMP_SLOTS);
+  HIPCHK(e, hipMemcpy(h.data(), cx.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemset(cx.stamps, 0, h.size() * sizeof(unsigned long long)));
+  cx.stamps_dirty = false;
+  for (int i = 0; i < STAMP_SLOTS; ++i) {
+    if (!h[2 * i + 1] || !h[2 * i]) continue;
+    const unsigned long long t0 = ~h[2 * i], t1 = h[2 * i + 1];
+    if (!e->stamp_base) e->stamp_base = t0;
+    if (e->stamp_spans.size() < 3 * (size_t)(1 << 20)) {
+      e->stamp_spans.push_back((float)i);
+      e->stamp_spans.push_back((float)((double)((long long)(t0 - e->stamp_base)) * 0.01));
+      e->stamp_spans.push_back((float)((double)((long long)(t1 - e->stamp_base)) * 0.01));
+    }
+  }
+  return RTP_OK;
+}
+
 void fill_problem(const rtp_engine* e, const Ctx& cx, const ConvOp& c, ConvProblem* pr) {
   memset(pr, 0, sizeof(*pr));
   pr->in = cx.arena + e->tensors[c.in_tensor].offset;
@@ -1053,6 +1085,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   }
   P.relu = A.relu ? 1 : 0;
   P.clkprobe = g_clkprobe;
+  P.stamp = stamp_slot(e, cx, (int)(&s - e->steps.data()));
   P.nimg = nimg;
   {
     static const char* rot = RTP_EXP_ENV("RTP_CONV_ROTATE");
@@ -1090,6 +1123,7 @@ int launch_pw2_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
   P.CoutP = 64;
   P.tiles_per_img = (int)(((long)g.H * g.Wp + 63) / 64);
   P.relu = C.relu ? 1 : 0;
+  P.stamp = stamp_slot(e, cx, (int)(&s - e->steps.data()));
   P.nimg = nimg;
   const int firsts[2] = {s.a, s.b};
   for (int q = 0; q < 2; ++q) {
@@ -1161,6 +1195,7 @@ int launch_first_step(rtp_engine* e, Ctx& cx, const Step& s, const float* input_
   Q.out = (_Float16*)(cx.arena + to.offset);
   Q.Cp = to.stride();
   Q.relu = c.relu ? 1 : 0;
+  Q.stamp = stamp_slot(e, cx, (int)(&s - e->steps.data()));
   HIPCHK(e, launch_conv_first(Q, cx.stream));
   return RTP_OK;
 }
@@ -1227,6 +1262,7 @@ NmsParams nms_params(rtp_engine* e, Ctx& cx, int sj) {
   np.max_peaks = e->max_peaks; np.nstrips = e->nstrips; np.strip_rows = e->strip_rows; np.threshold = e->nms_threshold;
   np.probe = nullptr;
   np.clear_flag = nullptr;
+  np.stamp = stamp_slot(e, cx, 64 + 8 * sj);
   return np;
 }
 int run_nms(rtp_engine* e, Ctx& cx, int sj = 0) {
@@ -1244,6 +1280,7 @@ ConnectParams connect_params(rtp_engine* e, Ctx& cx, int sj) {
   cp.max_peaks = e->max_peaks; cp.net_w = e->cfg.net_w; cp.net_h = e->cfg.net_h; cp.disp_w = e->cfg.disp_w; cp.disp_h = e->cfg.disp_h;
   cp.inter_threshold = e->inter_threshold; cp.inter_min_above = e->inter_min_above; cp.min_subset_cnt = e->min_subset_cnt;
   cp.min_subset_score = e->min_subset_score; cp.max_people = RTP_MAX_PEOPLE;
+  cp.stamp = stamp_slot(e, cx, 64 + 8 * sj + 2);
   return cp;
 }
 int run_connect(rtp_engine* e, Ctx& cx, int sj = 0) {
@@ -1490,6 +1527,8 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   HIPCHK(e, hipMemset(cx.lowres, 0, low_floats * sizeof(float)));
   for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.ev[i]));
   for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.gev[i]));
+  HIPCHK(e, hipMalloc((void**)&cx.stamps, 2 * STAMP_SLOTS * sizeof(unsigned long long)));
+  HIPCHK(e, hipMemset(cx.stamps, 0, 2 * STAMP_SLOTS * sizeof(unsigned long long)));
   cx.slot.resize(e->B);
   for (int j = 0; j < e->B; ++j) {
     int rc;
@@ -1539,7 +1578,7 @@ void free_ctx(Ctx& cx) {
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   for (hipGraphExec_t& g : cx.gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-  void* dptrs[] = {cx.arena, cx.input, cx.lowres};
+  void* dptrs[] = {cx.arena, cx.input, cx.lowres, cx.stamps};
   for (void* p : dptrs) if (p) (void)hipFree(p);
   if (cx.host_in) (void)hipHostFree(cx.host_in);
   for (int i = 0; i < 2; ++i) if (cx.ev[i]) (void)hipEventDestroy(cx.ev[i]);
@@ -1658,9 +1697,9 @@ int enqueue_preprocess(rtp_engine* e, Ctx& cx, int sj, const unsigned char* bgr,
   if (w == e->cfg.disp_w && h == e->cfg.disp_h) sl.disp_cur = sl.frame_dev;   // identity warp (20 us per 720p frame saved)
   else {
     sl.disp_cur = sl.disp_dev;
-    HIPCHK(e, launch_warp(sl.frame_dev, w, h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.in_stream));
+    HIPCHK(e, launch_warp(stamp_slot(e, cx, 200 + 2 * sj), sl.frame_dev, w, h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.in_stream));
   }
-  HIPCHK(e, launch_area_pad(sl.disp_cur, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.in_stream));
+  HIPCHK(e, launch_area_pad(stamp_slot(e, cx, 200 + 2 * sj + 1), sl.disp_cur, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.in_stream));
   cx.in_pending = true;
   return RTP_OK;
 }
@@ -1679,9 +1718,9 @@ int flush_prep(rtp_engine* e, Ctx& cx, bool force) {
     if (sl.pend_w == e->cfg.disp_w && sl.pend_h == e->cfg.disp_h) sl.disp_cur = sl.frame_dev;
     else {
       sl.disp_cur = sl.disp_dev;
-      HIPCHK(e, launch_warp(sl.frame_dev, sl.pend_w, sl.pend_h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
+      HIPCHK(e, launch_warp(stamp_slot(e, cx, 200 + 2 * (int)sj), sl.frame_dev, sl.pend_w, sl.pend_h, rtp_internal_warp_inverse_scale(s), e->warp_tab_dev, sl.disp_dev, e->cfg.disp_w, e->cfg.disp_h, cx.stream));
     }
-    HIPCHK(e, launch_area_pad(sl.disp_cur, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.stream));
+    HIPCHK(e, launch_area_pad(stamp_slot(e, cx, 200 + 2 * (int)sj + 1), sl.disp_cur, e->cfg.disp_w, e->cfg.disp_h, e->area_scales.data(), e->N, dst, e->cfg.net_w, e->cfg.net_h, cx.stream));
     sl.copy_pending = false;
   }
   return RTP_OK;
@@ -1804,6 +1843,12 @@ int open_slot(rtp_engine* e, int* ci, int* sj) {
       if (idle) e->open_ctx = (int)i;
     }
     if (e->open_ctx < 0) return fail(e, RTP_EAGAIN, "all %zu batch contexts (%d frames each) are busy", e->ctx.size(), e->B);
+    if (e->stamp_probe) {   // the context's previous batch is complete: read its kernels' residency stamps before anything of the new batch is launched
+      Ctx& c = e->ctx[e->open_ctx];
+      const int rc = stamp_harvest(e, c);
+      if (rc) return rc;
+      c.stamps_dirty = true;
+    }
   }
   *ci = e->open_ctx;
   *sj = e->ctx[e->open_ctx].filled;
@@ -2874,6 +2919,37 @@ int rtp_busy_probe(rtp_engine* e, int enable, float* spans, int cap) {
   }
   const int n = (int)(e->busy_spans.size() / 3);
   if (spans) memcpy(spans, e->busy_spans.data(), sizeof(float) * 3 * (size_t)std::min(n, std::max(cap, 0)));
+  return n;
+}
+
+// Kernel residency without a profiler.  enable = 1: on + reset (idle engine; the batch graphs are re-captured with the
+// stamp slots in their launches), 0: off (graphs re-captured without), -1: harvest every idle context and read.  spans (may be NULL): up to
+// `cap` triples {slot, start_us, end_us}: for every kernel launch of the per-frame path since the probe was switched on, the wall-clock time
+// (100 MHz, one clock for all XCDs) at which its FIRST workgroup started and its LAST workgroup ended, written by the workgroups themselves
+// (kernels.h KStamp).  slot: < 64 = plan step (rtp_plan_summary order), 64 + 8 j + k = frame j's strip / write / pairs / match / assemble
+// kernel, 200 + 2 j + k = frame j's warp / area-pad kernel.  The union of the spans over the wall = the share of the time in which at least one
+// kernel was resident on the chip.  Returns the number of triples.
+int rtp_stamp_probe(rtp_engine* e, int enable, float* spans, int cap) {
+  if (!e) return RTP_EINVAL;
+  int rc;
+  if ((rc = use_device(e))) return rc;
+  if (enable >= 0) {
+    if (!e->fifo.empty()) return fail(e, RTP_EAGAIN, "the stamp probe can only be switched on an idle engine");
+    if ((enable == 1) != e->stamp_probe || enable == 1) {
+      if ((rc = invalidate_graphs(e))) return rc;   // the slot pointers are launch arguments: baked into the captured graphs
+      e->stamp_probe = enable == 1;
+      for (Ctx& cx : e->ctx) {
+        if (!cx.stamps) continue;
+        HIPCHK(e, hipMemset(cx.stamps, 0, 2 * STAMP_SLOTS * sizeof(unsigned long long)));
+        cx.stamps_dirty = false;
+      }
+      if (enable == 1) { e->stamp_spans.clear(); e->stamp_base = 0; }
+    }
+  } else if (e->fifo.empty()) {
+    for (Ctx& cx : e->ctx) if ((rc = stamp_harvest(e, cx))) return rc;
+  }
+  const int n = (int)(e->stamp_spans.size() / 3);
+  if (spans) memcpy(spans, e->stamp_spans.data(), sizeof(float) * 3 * (size_t)std::min(n, std::max(cap, 0)));
   return n;
 }
 

@@ -16,6 +16,22 @@
 
 namespace rtp {
 
+// Kernel residency stamps (rtp_stamp_probe, bench.py `idle_frac_kernel_stamps`): when a launch carries a slot pointer, thread 0 of every
+// workgroup folds the 100 MHz wall clock (s_memrealtime: one clock for all XCDs, tools/clock_sync_probe.hip) into the slot when the
+// workgroup starts and when it ends: slot[0] = max(~start) = ~(first workgroup's start), slot[1] = max(end) = the last workgroup's end.
+// Null pointer (every launch outside a probe run): one scalar compare per workgroup.
+#if defined(__HIPCC__)
+struct KStamp {
+  unsigned long long* s;
+  __device__ __forceinline__ explicit KStamp(unsigned long long* p) : s(p) {
+    if (s && threadIdx.x == 0 && threadIdx.y == 0) atomicMax(s, ~wall_clock64());
+  }
+  __device__ __forceinline__ ~KStamp() {
+    if (s && threadIdx.x == 0 && threadIdx.y == 0) atomicMax(s + 1, wall_clock64());
+  }
+};
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Activation layout in HBM: NHWC with a zero spatial halo, one geometry per resolution level.
 //   element (n, y, x, c) lives at  base + ((n*Hp + y+halo)*Wp + x+halo)*Cp + c
@@ -83,6 +99,7 @@ struct ConvParams {
   int pool, pool_wq, pool_Wp, pool_halo;
   long pool_img_pix;
   int diag;    // experiments build (env RTP_EPI_DIAG; timing only, wrong results): 1 = the epilogue computes but does not store, 2 = no epilogue at all
+  unsigned long long* stamp;     // kernel residency slot (KStamp) or null
   unsigned long long* clkprobe;  // diagnostics: {shader clock cycles, wall clock ticks} of workgroup 0 (spec ring kernels)
 };
 
@@ -140,6 +157,7 @@ struct FirstParams {
   _Float16* out;        // halo'd NHWC destination, padded pixel 0
   int Cp;               // its channels per pixel (elements)
   int relu;
+  unsigned long long* stamp;  // kernel residency slot (KStamp) or null
 };
 hipError_t launch_conv_first(const FirstParams& Q, hipStream_t stream);
 int conv_first_channel_of_row(int i);
@@ -169,9 +187,9 @@ struct AreaScale {                    // cv::resize(INTER_AREA) tables of one py
   int linear;
   const int* lx; const int* ly;
 };
-hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
+hipError_t launch_warp(unsigned long long* stamp, const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
                        hipStream_t stream);
-hipError_t launch_area_pad(const unsigned char* disp, int dw, int dh, const AreaScale* scales, int nscales, float* out, int net_w, int net_h,
+hipError_t launch_area_pad(unsigned long long* stamp, const unsigned char* disp, int dw, int dh, const AreaScale* scales, int nscales, float* out, int net_w, int net_h,
                            hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
@@ -218,6 +236,7 @@ struct NmsParams {
   int src_planes, H, W, num_parts, max_peaks, nstrips, strip_rows;
   float threshold;
   unsigned long long* probe;  // diagnostics (RTP_NMS_PROBE): wall-clock stamps of the phases of one strip workgroup, [0] = count
+  unsigned long long* stamp;  // kernel residency slots (KStamp) or null: [0,1] strip kernel, [2,3] write kernel
   int* clear_flag;            // production chain: the connect kernels' people counter / error flag, reset here (the write kernel runs right in
                               // front of them on the same stream) instead of by a 4-byte fill launch of its own between the two
 };
@@ -228,6 +247,7 @@ hipError_t launch_nms(const NmsParams& p, hipStream_t stream);
 hipError_t launch_nms_fused(const NmsParams& p, const ResizeParams& r, hipStream_t stream);
 
 struct ConnectParams {
+  unsigned long long* stamp;  // kernel residency slots (KStamp) or null: [0,1] pairs, [2,3] match, [4,5] assemble
   int counter_cleared;  // 1: *num_people was reset by the NMS write kernel in front of this chain (NmsParams::clear_flag)
   int* tickets;         // [num_limbs + 1] zeros (device): non-null = the production chain runs as ONE launch (connect_chain_kernel): per-limb tickets of
                         // the pair workgroups + one of the limbs; the kernel leaves them zero again

@@ -372,6 +372,7 @@ struct YTab { int o0, o1, o2, o3; float dy; };  // one output row: offsets of it
 struct XTab { int xn1; float dx; };  // axis_nb's clamped integer position (before padding) and fraction of one output column
 #define NMS_STAMP() do { if (probe_me) { __syncthreads(); if (threadIdx.x == 0 && stamp_i < 30) p.probe[++stamp_i] = wall_clock64(); } } while (0)
 __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, ResizeParams r) {
+  const KStamp kstamp_(p.stamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const bool probe_me = p.probe && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;  // uniform
   int stamp_i = 0;
@@ -660,6 +661,7 @@ __global__ __launch_bounds__(256) void nms_fused_strip_kernel(NmsParams p, Resiz
 // Write kernel: the 49 window values of every kept peak are evaluated on demand by all threads,
 // then one thread per peak accumulates them in the reference's (dy, dx) order.
 __global__ __launch_bounds__(256) void nms_fused_write_kernel(NmsParams p, ResizeParams r) {
+  const KStamp kstamp_(p.stamp ? p.stamp + 2 : nullptr);
   extern __shared__ int dyn_i[];
   int* prefix = dyn_i;                                   // [nstrips+1]
   float* win = (float*)(dyn_i + p.nstrips + 1);          // [max_peaks][50]: 49 window values + centre
@@ -933,6 +935,7 @@ __device__ __forceinline__ void connect_pairs_body(const ConnectParams& p, const
 }
 template <bool FUSED>
 __global__ __launch_bounds__(PAIRS_WG) void connect_pairs_kernel(ConnectParams p, ResizeParams r, int stage) {
+  const KStamp kstamp_(p.stamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   connect_pairs_body<FUSED>(p, r, stage, lds_raw);
 }
@@ -1132,6 +1135,7 @@ __device__ __forceinline__ void connect_match_limb(const ConnectParams& p, const
 // hold 19 CUs while convolution launches need 248 at once.  Result: fewer workgroups are SLOWER (19: 1053 frames/s, 8: 1028, 4: 1017,
 // 2: 973) — what the chain costs is its latency (a frame holds its pipeline slot until its joints are on the host), not the CUs.
 __global__ __launch_bounds__(256) void connect_match_kernel(ConnectParams p) {
+  const KStamp kstamp_(p.stamp ? p.stamp + 2 : nullptr);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   for (int k = blockIdx.x; k < p.num_limbs; k += gridDim.x) {
     connect_match_limb(p, k, lds_raw);
@@ -1293,6 +1297,7 @@ __device__ __forceinline__ void connect_assemble_body(const ConnectParams& p, un
   if (tid == 0) *p.num_people = out < p.max_people ? out : p.max_people;
 }
 __global__ __launch_bounds__(256) void connect_assemble_kernel(ConnectParams p) {
+  const KStamp kstamp_(p.stamp ? p.stamp + 4 : nullptr);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   connect_assemble_body(p, lds_raw);
 }

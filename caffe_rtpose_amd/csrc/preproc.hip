@@ -16,8 +16,9 @@
 
 namespace rtp {
 
-__global__ __launch_bounds__(256) void warp_cubic_kernel(const unsigned char* __restrict__ src, int sw, int sh, double inv,
+__global__ __launch_bounds__(256) void warp_cubic_kernel(unsigned long long* stamp, const unsigned char* __restrict__ src, int sw, int sh, double inv,
                                                          const short* __restrict__ tab2d, unsigned char* __restrict__ dst, int dw, int dh) {
+  const KStamp kstamp_(stamp);
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= dw) return;
@@ -52,9 +53,10 @@ __global__ __launch_bounds__(256) void warp_cubic_kernel(const unsigned char* __
 }
 
 // One thread per pixel of the (net_w x net_h) frame of scale `blockIdx.z`.
-__global__ __launch_bounds__(256) void area_pad_kernel(const unsigned char* __restrict__ disp, int dw, int dh, AreaScale sc0, AreaScale sc1,
+__global__ __launch_bounds__(256) void area_pad_kernel(unsigned long long* stamp, const unsigned char* __restrict__ disp, int dw, int dh, AreaScale sc0, AreaScale sc1,
                                                        AreaScale sc2, AreaScale sc3, int nscales_in_launch, float* __restrict__ out, int net_w,
                                                        int net_h, int scale_base) {
+  const KStamp kstamp_(stamp);
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   const int si = blockIdx.z;
@@ -121,14 +123,14 @@ __global__ __launch_bounds__(256) void area_pad_kernel(const unsigned char* __re
   for (int c = 0; c < 3; ++c) o[c * plane] = r3[c] / 256.0f - 0.5f;
 }
 
-hipError_t launch_warp(const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
+hipError_t launch_warp(unsigned long long* stamp, const unsigned char* src, int sw, int sh, double inv, const short* tab2d, unsigned char* dst, int dw, int dh,
                        hipStream_t stream) {
   dim3 grid((dw + 255) / 256, dh);
-  hipLaunchKernelGGL(warp_cubic_kernel, grid, dim3(256), 0, stream, src, sw, sh, inv, tab2d, dst, dw, dh);
+  hipLaunchKernelGGL(warp_cubic_kernel, grid, dim3(256), 0, stream, stamp, src, sw, sh, inv, tab2d, dst, dw, dh);
   return hipGetLastError();
 }
 
-hipError_t launch_area_pad(const unsigned char* disp, int dw, int dh, const AreaScale* scales, int nscales, float* out, int net_w, int net_h,
+hipError_t launch_area_pad(unsigned long long* stamp, const unsigned char* disp, int dw, int dh, const AreaScale* scales, int nscales, float* out, int net_w, int net_h,
                            hipStream_t stream) {
   for (int base = 0; base < nscales; base += 4) {
     const int n = nscales - base < 4 ? nscales - base : 4;
@@ -139,7 +141,7 @@ hipError_t launch_area_pad(const unsigned char* disp, int dw, int dh, const Area
     const AreaScale& c = n > 2 ? scales[base + 2] : z;
     const AreaScale& d = n > 3 ? scales[base + 3] : z;
     dim3 grid((net_w + 255) / 256, net_h, n);
-    hipLaunchKernelGGL(area_pad_kernel, grid, dim3(256), 0, stream, disp, dw, dh, a, b, c, d, n, out, net_w, net_h, base);
+    hipLaunchKernelGGL(area_pad_kernel, grid, dim3(256), 0, stream, stamp, disp, dw, dh, a, b, c, d, n, out, net_w, net_h, base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

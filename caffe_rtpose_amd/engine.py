@@ -557,6 +557,16 @@ class Engine:
             lib.rtp_busy_probe(self.h, -1, _f(out), n)
         return out
 
+    def stamp_probe(self, enable=-1):
+        """rtp_stamp_probe: kernel residency spans as an [n][3] float32 array {slot, start_us, end_us} (device-side wall-clock stamps)."""
+        n = lib.rtp_stamp_probe(self.h, enable, None, 0)
+        if n < 0:
+            raise RtpError(n, lib.rtp_last_error(self.h).decode())
+        out = np.zeros((n, 3), np.float32)
+        if n:
+            lib.rtp_stamp_probe(self.h, -1, _f(out), n)
+        return out
+
     def bench_dominant_conv(self, iters=50):
         ms = C.c_float()
         fl = C.c_double()

@@ -354,6 +354,13 @@ int rtp_kernel_timing_steps(const rtp_engine* e, double* ms, long* launches, int
  * the end of its conv stack; kind 1 = one frame's post-processing chain incl. the D2H of its joints.  Returns the number of triples
  * (at most `cap` are copied to `spans`, which may be NULL). */
 int rtp_busy_probe(rtp_engine* e, int enable, float* spans, int cap);
+/* Kernel RESIDENCY without a profiler: while on, thread 0 of every workgroup of every kernel of the per-frame path (device pre-processing,
+ * conv stack, ImResize+Nms, connect) folds the chip's 100 MHz wall clock into a per-launch slot — first workgroup start, last workgroup
+ * end.  enable = 1: on + reset (idle engine only; the batch graphs are re-captured with the slots), 0: off, -1: harvest + read.  spans:
+ * {slot, start_us, end_us} triples; slot < 64 = plan step (rtp_plan_summary order), 64 + 8 j + k = frame j's strip / write / pairs / match /
+ * assemble kernel, 200 + 2 j + k = frame j's warp / area-pad kernel.  1 - union(spans) / wall = the share of the time with NO kernel on the
+ * chip (bench.py `idle_frac_kernel_stamps`).  No reference counterpart (measurement only).  Returns the number of triples. */
+int rtp_stamp_probe(rtp_engine* e, int enable, float* spans, int cap);
 /* Host float -> OCP e4m3 (round to nearest even, clamped to +-448): how the fp8 weight copies of split layers are made. */
 int rtp_debug_f32_to_e4m3(const float* in, unsigned char* out, int n);
 

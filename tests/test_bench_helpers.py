@@ -85,3 +85,18 @@ def test_the_bench_line_is_compact_and_keeps_the_contract_keys():
     fat["cpu_baseline"]["sample"] = "y" * 5000
     fat["roofline"]["classes"] = {f"class {i} " + "z" * 40: v for i, v in enumerate(list(full["roofline"]["classes"].values()) * 4)}
     assert len(b.compact_line(fat)) <= b.LINE_LIMIT
+
+
+def test_stamp_account_counts_the_wall_with_no_kernel_resident():
+    """bench.py's `idle_frac_kernel_stamps`: union of device-side residency spans {slot, start_us, end_us}."""
+    b = _bench()
+    spans = []
+    for i in range(200):      # a conv kernel 80 us of every 100, a post kernel inside the gap for 5 us, one overlapping the conv kernel
+        spans.append((3, i * 100.0, i * 100.0 + 80.0))
+        spans.append((64, i * 100.0 + 85.0, i * 100.0 + 90.0))
+        spans.append((66, i * 100.0 + 40.0, i * 100.0 + 60.0))
+    acc = b.stamp_account(np.array(spans, np.float32))
+    assert abs(acc["resident_frac"] - 0.85) < 0.01 and abs(acc["idle_frac"] - 0.15) < 0.01
+    assert abs(acc["conv_resident_frac"] - 0.80) < 0.01 and abs(acc["post_resident_frac"] - 0.25) < 0.01
+    assert abs(acc["kernels_resident_avg"] - 1.05) < 0.02 and abs(acc["kernels_resident_hist"]["2"] - 0.20) < 0.01
+    assert b.stamp_account(np.zeros((3, 3), np.float32)) is None

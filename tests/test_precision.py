@@ -303,4 +303,32 @@ def test_per_step_timing_and_busy_probe_feed_the_bench_line():
     with pytest.raises(r.RtpError):       # idle engines only
         e.busy_probe(1)
     e.collect()
+    # kernel residency stamps (rtp_stamp_probe): every launch of the pipelined loop leaves {first workgroup start, last workgroup end};
+    # results must not depend on the probe (same joints), the stamps must be ordered inside a batch, and the account must be a fraction < 1
+    e.submit(x, tag=5)
+    _, n_ref, j_ref = e.collect()
+    assert len(e.stamp_probe(1)) == 0
+    sub = col = 0
+    while col < 120:
+        while sub < 120 and e.in_flight() < 6:
+            e.submit(x, tag=sub)
+            sub += 1
+        _, n_got, j_got = e.collect()
+        assert n_got == n_ref and np.array_equal(j_got, j_ref)
+        col += 1
+    st = e.stamp_probe(-1)
+    e.stamp_probe(0)
+    nsteps = len(plan)
+    conv = st[st[:, 0] < 64]
+    assert len(conv) >= (120 // B - 4) * (nsteps - 1) and (st[:, 2] > st[:, 1]).all()
+    assert {64.0, 65.0, 66.0, 67.0, 68.0} <= set(np.unique(st[:, 0]))       # strip, write, pairs, match, assemble of frame 0 of the batches
+    d = st[:, 2] - st[:, 1]
+    assert 5.0 < np.median(d[st[:, 0] < 64]) < 200.0                          # microseconds: a conv launch lives tens of microseconds
+    acc2 = bench.stamp_account(st)
+    print(f"[stamps] resident {acc2['resident_frac']:.4f} (conv {acc2['conv_resident_frac']:.3f}, post {acc2['post_resident_frac']:.3f}), "
+          f"{acc2['kernels_resident_avg']:.2f} kernels resident on average, hist {acc2['kernels_resident_hist']}")
+    assert 0.5 < acc2["resident_frac"] < 1.0 and acc2["idle_frac"] > 0.0
+    e.submit(x, tag=6)                     # probe off again: graphs re-captured without slots, same results
+    _, n_got, j_got = e.collect()
+    assert n_got == n_ref and np.array_equal(j_got, j_ref)
     e.close()
