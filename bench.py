@@ -568,7 +568,7 @@ def compact_line(out, detail_paths=()):
             "scaling", "vs_baseline", "dtype", "data")
     line = {k: rnd(out[k], 6) for k in keep if k in out}
     cfg = out.get("config") or {}
-    line["config"] = {k: cfg[k] for k in ("precision", "input", "batch_frames", "frames_in_flight", "num_scales", "exec", "parallelism") if k in cfg}
+    line["config"] = {k: cfg[k] for k in ("precision", "input", "batch_frames", "frames_in_flight", "num_scales", "exec", "hw_queues", "parallelism") if k in cfg}
     line["config"]["workload"] = str(cfg.get("workload", ""))[:300]
     roof = out.get("roofline") or {}
     r_ = {k: rnd(roof.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_2q", "ms_per_launch", "launches_timed",
@@ -697,6 +697,9 @@ def main():
     ap.add_argument("--devices", default=None, help="device of every rank, e.g. 0,0: lets N ranks share one GPU (a test hook like rtpose.bin --devices; default: rank i uses device LOCAL_RANK)")
     ap.add_argument("--broadcast_weights", action="store_true", help="N > 1: rank 0's packed weight arena is broadcast to the other ranks (rtp_weight_blob_export / import) "
                     "instead of every rank keeping the copy it packed itself; one-time, outside the timed region")
+    ap.add_argument("--hw_queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this process (set before the first HIP call unless the environment already has it). "
+                    "Default: 6 for batches of 2 (the engine's ten streams then put every conv stack on a hardware queue of its own: +6 %% frames/s), the runtime's 4 "
+                    "otherwise (batches of 5 lose 25 %% on 6) — a measured setting like --in_flight (profiles/r06_experiments.txt)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_sub_results", action="store_true")
     ap.add_argument("--no_parity", action="store_true", help="skip the people-level parity verdict against the CPU oracle chain (3 frames)")
@@ -704,6 +707,9 @@ def main():
     args = ap.parse_args()
     if args.batch_frames is None:
         args.batch_frames = 5 if args.model == "mpi" else (2 if args.num_scales == 1 else 1)
+    if args.hw_queues is None:
+        args.hw_queues = 6 if args.batch_frames == 2 else 4
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))   # (the HIP runtime reads it once, at its first call: torch and the engine are imported below)
     if args.in_flight is None:
         table = {("mpi", 5): 10, ("coco", 2): 7 if args.num_scales == 1 else 6, ("coco", 1): 7 if args.num_scales == 1 else 3}   # measured optima (profiles/r03_in_flight.txt)
         args.in_flight = max(table.get((args.model, args.batch_frames), 2 * args.batch_frames), args.batch_frames)
@@ -953,6 +959,7 @@ def main():
                        "workload": f"{args.model.upper()} {W}x{H}, {args.num_scales} scale(s), synthetic 720p video: {src} -> conv stack+ImResize+NMS+connect -> joints on the host; "
                                    f"precision mode {args.precision}, {args.in_flight} frames in flight/GPU in batches of {args.batch_frames}, {args.exec_mode} launches, synthetic weights",
                        "input": args.input, "batch_frames": args.batch_frames, "frames_in_flight": args.in_flight, "num_scales": args.num_scales, "exec": args.exec_mode,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"frame-sharded replicas x{world}"},
             "latency_ms": {"p50_pipelined": float(np.percentile(m["lat"], 50) * 1e3), "p95_pipelined": float(np.percentile(m["lat"], 95) * 1e3),
                            "batch_on_device": stage["total"]},

@@ -1431,6 +1431,17 @@ int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev, bool materiali
 // Experiments build only: RTP_CONV_PRIO / RTP_POST_PRIO = a stream priority (hipDeviceGetStreamPriorityRange: lower number = higher
 // priority); RTP_POST_CUS = n: the post-processing streams may only use n CUs (hipExtStreamCreateWithCUMask; the KFD interleaves the
 // mask bits over the XCDs, so the low 8 bits are one CU in each of the 8 XCDs).  Both measured worse than plain streams.
+// ---- hardware queues ------------------------------------------------------------------------------------------------------------------
+// A hardware queue runs the kernels of ITS streams one after the other, and the HIP runtime attaches every new stream to the queue with the
+// fewest streams (tools/hwq_probe.hip: the first Q streams take queues 0..Q-1, later ones Q-1, Q-2, .., 0, Q-1, ..; Q = GPU_MAX_HW_QUEUES,
+// default 4, read once at the process's first HIP call).  A batch context creates its conv stream, then one stream per further frame of the
+// batch; with batches of 2 and 5 contexts that is 10 streams.  On 4 queues every conv stack shares its queue with another context's
+// conv stack or chain; on 6 queues the five conv stacks sit on five different queues, each shared with ONE other context's frame-1 chain:
+// +6 % frames/s (1087 -> 1154, same box, three repetitions; profiles/r06_experiments.txt).  Dealing streams to explicit conv / post queue
+// classes (conv stacks alone on their queues) measured WORSE (900 against 1067), as round 5's RTP_STREAM_PLAN did: a chain that waits for
+// nothing but its own batch holds CUs exactly when the next batch's stack wants them.  The host programs therefore only choose the queue
+// COUNT per workload (bench.py --hw_queues, rtpose.bin: 6 for batches of 2, the runtime's 4 otherwise — batches of 5 lose 25 % on 6), the
+// engine keeps its creation order.
 hipError_t make_stream(hipStream_t* s, bool post) {
 #ifdef RTP_EXPERIMENTS
   if (post) {

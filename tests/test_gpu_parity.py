@@ -902,3 +902,5 @@ def test_deferred_preprocessing_and_staging_streams_do_not_change_results():
     assert run(["2", "7"], RTP_LIB=exp, RTP_CHAIN_CONNECT="1") == run(["2", "7"])     # pairs -> match -> assemble as one launch (tickets)
     assert run(["2", "7"], RTP_LIB=exp, RTP_IN_STREAM="1") == run(["2", "7"])
     assert run(["2", "7"], RTP_LIB=exp, RTP_IN_STREAM="2", RTP_PREP_DEFER="1") == run(["2", "7"])
+    # the hardware-queue count bench.py / rtpose.bin choose for batches of 2 (GPU_MAX_HW_QUEUES=6: which streams share a queue changes, results do not)
+    assert run(["2", "7"], GPU_MAX_HW_QUEUES="6") == run(["2", "7"], GPU_MAX_HW_QUEUES="4")
