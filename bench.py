@@ -874,13 +874,17 @@ def main():
         # one-time weight distribution (outside the timed region): rank 0 reads / generates, packs (and calibrates) ONCE; the other ranks learn its
         # plan (precision mode + split set), are created without weights (rtp_config.defer_weights) and import rank 0's packed arena
         t0 = time.perf_counter()
-        meta = np.zeros(4096, np.uint8)
         eng = None
+        enc = b""
         if rank == 0:
             eng = make_engine(args.precision, args.num_scales, args.scale_gap, args.batch_frames, args.in_flight)
             rules, mode = eng.split_layers()
             enc = f"{mode}|{rules}".encode()
-            meta[:len(enc)] = np.frombuffer(enc, np.uint8)
+        nlen = torch.tensor([len(enc)], dtype=torch.int64, device=red_dev)     # the rule list has no fixed size: its length first
+        dist.broadcast(nlen, 0)
+        meta = np.zeros(int(nlen.item()), np.uint8)
+        if rank == 0:
+            meta[:] = np.frombuffer(enc, np.uint8)
         meta = broadcast_bytes(meta, 0, dist, red_dev)
         if rank != 0:
             mode, rules = bytes(meta).rstrip(b"\0").decode().split("|", 1)

@@ -3302,8 +3302,14 @@ const char* rtp_calibration_report(const rtp_engine* e) { return e ? e->calib_re
 // The split set in force (rule list of rtp_config.split_layers syntax) and the precision mode (a calibration may have changed both).
 int rtp_get_split_layers(const rtp_engine* e, char* buf, size_t buflen, int* precision) {
   if (!e) return RTP_EINVAL;
-  if (buf && buflen) snprintf(buf, buflen, "%s", e->split_rules.c_str());
   if (precision) *precision = e->mode;
+  if (buf && buflen) {
+    if (e->split_rules.size() + 1 > buflen) {   // never a silently truncated rule list: the receiver would build another plan
+      buf[0] = 0;
+      return fail(const_cast<rtp_engine*>(e), RTP_ERANGE, "rtp_get_split_layers: the rule list needs %zu bytes, the buffer has %zu", e->split_rules.size() + 1, buflen);
+    }
+    snprintf(buf, buflen, "%s", e->split_rules.c_str());
+  }
   return RTP_OK;
 }
 

@@ -174,6 +174,7 @@ struct Global {
   std::vector<int> per_worker;  // frames each worker submitted (dynamic pull from the one shared queue)
   std::atomic<rtp_engine*> engine0{nullptr};  // --share_weights: worker 0's engine once it is up (idle until every worker is ready)
   std::atomic<int> weights_shared{0};
+  std::atomic<int> share_done{0};      // receiving workers that are through with worker 0's engine (copied, or failed): worker 0 keeps it alive until all are
   std::atomic<int> workers_ready{0};  // workers start pulling once EVERY engine is up (engine creation takes seconds, short inputs milliseconds)
   std::atomic<bool> producer_done{false};
   double first_commit = 0;                     // steady-state window: first frame committed .. last file written
@@ -350,15 +351,20 @@ void worker(int widx, int device, int* status) {
   // --share_weights: ONE read + pack of the model for N replicas.  Worker 0 loads (and, with --calibrate or a model file, calibrates);
   // the others wait for it, are created WITHOUT weights (rtp_config.defer_weights) on worker 0's final split set and take its packed
   // arena device to device before anybody submits a frame (worker 0's engine is idle until every worker is ready).
-  char src_rules[4096];
+  std::vector<char> src_rules(1 << 16);   // (a calibrated rule list names layer groups: a few hundred bytes; rtp_get_split_layers refuses a buffer that is too small)
   rtp_engine* src = nullptr;
+  struct ShareDone {   // counted on EVERY way out of this function once a receiving worker exists (worker 0 waits for the count before it destroys its engine)
+    bool armed = false;
+    ~ShareDone() { if (armed) G.share_done++; }
+  } share_done_guard;
   if (!dry && F.share_weights && widx != 0) {
+    share_done_guard.armed = true;
     while (!(src = G.engine0.load()) && !G.quit_threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     if (!src) { *status = 1; return; }   // worker 0 failed and everybody is quitting: nothing was copied, nothing is counted
     int prec = cfg.precision;
-    if (rtp_get_split_layers(src, src_rules, sizeof src_rules, &prec) != RTP_OK) { fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(src)); *status = 1; G.quit_threads = true; return; }
+    if (rtp_get_split_layers(src, src_rules.data(), src_rules.size(), &prec) != RTP_OK) { fprintf(stderr, "GPU %d: --share_weights: %s\n", device, rtp_last_error(src)); *status = 1; G.quit_threads = true; return; }
     cfg.precision = prec;
-    cfg.split_layers = src_rules;
+    cfg.split_layers = src_rules.data();
     cfg.calibrate_frames = -1;
     cfg.defer_weights = 1;
   }
@@ -380,6 +386,7 @@ void worker(int widx, int device, int* status) {
       }
       G.weights_shared++;
     }
+    if (widx != 0) { share_done_guard.armed = false; G.share_done++; }   // through with worker 0's engine
   }
   int num_parts = F.model == "mpi" ? 15 : 18;
   if (!dry) rtp_engine_info(e, &num_parts, nullptr, nullptr, nullptr, nullptr);
@@ -469,6 +476,8 @@ void worker(int widx, int device, int* status) {
     else std::this_thread::sleep_for(std::chrono::microseconds(200));
   }
   while (!inflight.empty()) collect_one();
+  if (e && F.share_weights && widx == 0 && !dry)   // a receiver may still be inside rtp_get_split_layers / rtp_copy_weights_from on this engine (error paths set quit_threads early)
+    while (G.share_done.load() < F.num_gpu - 1) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   if (e) rtp_engine_destroy(e);
 }
 

@@ -470,7 +470,7 @@ class Engine:
         return lib.rtp_calibration_report(self.h).decode()
 
     def split_layers(self):
-        buf = C.create_string_buffer(4096)
+        buf = C.create_string_buffer(1 << 16)   # (rtp_get_split_layers returns RTP_ERANGE instead of truncating)
         p = C.c_int()
         self._chk(lib.rtp_get_split_layers(self.h, buf, len(buf), C.byref(p)))
         return buf.value.decode(), p.value

@@ -245,6 +245,8 @@ int rtp_save_prototxt(const rtp_engine* e, const char* path);
 int rtp_calibrate_precision(rtp_engine* e, const float* frames_host, int nframes, float target, char* rules_out, size_t rules_len,
                             float* err_before, float* err_after);
 const char* rtp_calibration_report(const rtp_engine* e); /* what the last calibration tried and chose, as text */
+/* The rule list the engine runs (after calibration: the widened one) and its precision mode.  RTP_ERANGE (and an empty buf) if the list does
+ * not fit buflen bytes incl. the NUL: a truncated list would describe another plan. */
 int rtp_get_split_layers(const rtp_engine* e, char* buf, size_t buflen, int* precision);
 
 /* Caller-owned device buffers on the engine's device (replaces blobs()[0]->mutable_gpu_data() as a caller-filled H2D target,
