@@ -138,6 +138,15 @@ __device__ __forceinline__ void conv_store_dst(const ConvDst dd, int Cout, long 
           qh.z = pack4_fp8(hif[8], hif[9], hif[10], hif[11]); qh.w = pack4_fp8(hif[12], hif[13], hif[14], hif[15]);
           *(uint4*)qb = ql;
           *(uint4*)(qb + 64) = qh;
+        } else if (nvalid == 16 && (ch & 7) == 0 && (ch & 63) <= 48) {   // an 8-aligned slice of a concat tensor (L2 at channel 168): the 16 channels
+          unsigned char* qb = qrow + (ch >> 6) * 128 + (ch & 63);       // stay inside one 64-channel q group: 8-byte stores instead of 32 byte stores
+          uint2 l0, l1, h0, h1;
+          l0.x = pack4_fp8(lof[0], lof[1], lof[2], lof[3]); l0.y = pack4_fp8(lof[4], lof[5], lof[6], lof[7]);
+          l1.x = pack4_fp8(lof[8], lof[9], lof[10], lof[11]); l1.y = pack4_fp8(lof[12], lof[13], lof[14], lof[15]);
+          h0.x = pack4_fp8(hif[0], hif[1], hif[2], hif[3]); h0.y = pack4_fp8(hif[4], hif[5], hif[6], hif[7]);
+          h1.x = pack4_fp8(hif[8], hif[9], hif[10], hif[11]); h1.y = pack4_fp8(hif[12], hif[13], hif[14], hif[15]);
+          *(uint2*)qb = l0; *(uint2*)(qb + 8) = l1;
+          *(uint2*)(qb + 64) = h0; *(uint2*)(qb + 72) = h1;
         } else {
           for (int u = 0; u < nvalid; ++u) {
             const int cu = ch + u;

@@ -490,6 +490,15 @@ int build_plan(rtp_engine* e) {
     std::vector<int> internal_off(ins.size());
     int off = 0;
     for (int i : ord) { internal_off[i] = off; off += e->blob_dims[ins[i]].first; }
+    {  // every slice on an 8-channel boundary where the pad channels of the tensor pay for it (concat_stageK: conv4_4_CPM at 0, L1 at 128, L2 at
+       // 168 instead of 166, 192 channels either way): the producers' epilogues then write the slice with 16-byte stores instead of one 2-byte
+       // store + two fp8 byte stores per channel (conv_common.h conv_store_dst) — the branch tails' epilogue was 4.1 us of an 11 us workgroup
+       // for that reason.  The skipped channels are pad channels like the tail's: zero activations, zero weights (chmap never points at them).
+      std::vector<int> aligned(ins.size());
+      int a = 0;
+      for (int i : ord) { a = round_up(a, 8); aligned[i] = a; a += e->blob_dims[ins[i]].first; }
+      if (round_up(a, CALIGN) == round_up(off, CALIGN)) internal_off = aligned;
+    }
     const int tid = new_tensor(kv.first, e->blob_dims[kv.first].first, e->blob_dims[kv.first].second);
     e->blob_tensor[kv.first] = tid;
     int refc = 0;
@@ -771,6 +780,16 @@ int build_plan(rtp_engine* e) {
       if (!chain(s1.a, s2.a) || (s1.b >= 0 && !chain(s1.b, s2.b))) continue;
       if (s1.b >= 0 && (e->convs[s1.a].cout != e->convs[s1.b].cout)) continue;
       s1.type = 3; s1.a2 = s2.a; s1.b2 = s2.b;
+      // the middle blob (Mconv6_stageK / conv5_4_CPM) lives in LDS between the two GEMMs; nobody reads it from memory: it is written only
+      // when every blob must stay tappable (keep_blobs) — 32-128 KB of stores per workgroup and ~0.9 us of its ~11 us otherwise
+      for (int idx : {s1.a, s1.b}) {
+        if (idx < 0 || e->cfg.keep_blobs) continue;
+        const int mid = e->convs[idx].dsts[0].first;
+        bool read_elsewhere = false;
+        for (auto& c2 : e->convs) if (c2.in_tensor == mid && &c2 != &e->convs[idx == s1.a ? s1.a2 : s1.b2]) read_elsewhere = true;
+        for (auto& po : e->pools) if (po.in_tensor == mid) read_elsewhere = true;
+        if (!read_elsewhere) e->tensors[mid].written = false;
+      }
       for (int idx : {s1.a, s1.b}) if (idx >= 0) { ConvOp& A = e->convs[idx]; A.fused = 1; A.fused_chunks = A.cout / 128; A.CoutP = A.cout; }
       for (int idx : {s1.a2, s1.b2}) if (idx >= 0) { ConvOp& C = e->convs[idx]; C.fused = 2; C.fused_chunks = C.cin / 128; C.CoutP = 64; }
       e->steps.erase(e->steps.begin() + si + 1);
@@ -1136,7 +1155,7 @@ int launch_pw2_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
     Q.x_lo_off = F.split_a ? ti.lo_off() : 0;
     Q.w1[q] = e->dweights + F.w_off;
     Q.b1[q] = (const float*)(e->dweights + F.b_off);
-    Q.mid[q].base = cx.arena + tm.offset;
+    Q.mid[q].base = tm.written ? cx.arena + tm.offset : nullptr;   // (not materialised unless keep_blobs: the kernel skips the store)
     Q.mid[q].cstride = tm.stride();
     Q.mid[q].coff = 0;
     Q.mid[q].lo_off = tm.lo_off();
@@ -1281,6 +1300,10 @@ ConnectParams connect_params(rtp_engine* e, Ctx& cx, int sj) {
   cp.inter_threshold = e->inter_threshold; cp.inter_min_above = e->inter_min_above; cp.min_subset_cnt = e->min_subset_cnt;
   cp.min_subset_score = e->min_subset_score; cp.max_people = RTP_MAX_PEOPLE;
   cp.stamp = stamp_slot(e, cx, 64 + 8 * sj + 2);
+  {
+    static const char* pf = RTP_EXP_ENV("RTP_PAIRS_FULL");
+    cp.pairs_full = (pf && pf[0] == '1') ? 1 : 0;
+  }
   return cp;
 }
 int run_connect(rtp_engine* e, Ctx& cx, int sj = 0) {
@@ -2558,7 +2581,7 @@ int rtp_get_blob(rtp_engine* e, const char* name, float* out, size_t cap, int sh
   auto it = e->blob_tensor.find(name);
   if (it == e->blob_tensor.end()) return fail(e, RTP_EINVAL, "Unknown blob name %s", name);  // net.cpp blob_by_name warning
   const Tensor& t = e->tensors[it->second];
-  if (!t.written) return fail(e, RTP_EINVAL, "blob %s is not materialised: its convolution pools in the epilogue and writes only the pooled blob (create the engine with keep_blobs = 1 to tap it)", name);
+  if (!t.written) return fail(e, RTP_EINVAL, "blob %s is not materialised: its convolution pools in the epilogue and writes only the pooled blob, or it is the middle blob of a fused branch tail that lives in LDS (create the engine with keep_blobs = 1 to tap it)", name);
   Geom g = e->geom[t.level];
   g.N = e->N;  // the taps run one frame (slot 0 of the batch)
   const size_t n = (size_t)g.N * t.C * g.H * g.W;

@@ -268,6 +268,7 @@ struct ConnectParams {
   int* subset_cnt;     // [max_rows]
   int max_rows;
   int assemble_preload;  // set by launch_connect: the assembly kernel copies its inputs to LDS first
+  int pairs_full;        // experiments (RTP_PAIRS_FULL=1): the pair kernel evaluates all 10 samples of every pair (round 5's behaviour; same results)
   int diag_stages;       // diagnostics (RTP_DIAG_SKIP_POST): 0 = all kernels, 1 = pairs only, 2 = pairs + match, 3 = all
   int model;           // 0 COCO_18, 1 MPI_15
   int num_parts, num_limbs, max_peaks;

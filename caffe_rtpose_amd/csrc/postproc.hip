@@ -889,27 +889,33 @@ __device__ __forceinline__ void connect_pairs_body(const ConnectParams& p, const
       if (indef || mx < 0 || my < 0 || mx >= NW || my >= NH) { bad = true; mx = 0; my = 0; }
       idxs[lm] = my * NW + mx;
     }
-    float px[10], py[10];
-#pragma unroll
-    for (int lm = 0; lm < num_inter; lm++) {
-      if (FUSED) {  // the two PAF samples straight from the low-res maps (no resized map in memory)
-        const int my = idxs[lm] / NW, mx = idxs[lm] - my * NW;
-        if (stage) resized_pair(geo, r.num, lmap, lmap + r.num * lplane, lplane, my, mx, &px[lm], &py[lm]);
-        else resized_pair(geo, r.num, r.src + (long)mapIdx[2 * k] * lplane, r.src + (long)mapIdx[2 * k + 1] * lplane, (long)r.C * lplane, my, mx, &px[lm], &py[lm]);
-      } else {
-        px[lm] = map_x[idxs[lm]];
-        py[lm] = map_y[idxs[lm]];
-      }
-    }
+    // The 10 samples in order (rtpose.cpp:931-947).  A pair survives only with count > inter_min_above: once more samples have failed than
+    // that leaves room for, the pair is rejected whatever the remaining samples say, and the wave stops evaluating when that holds for EVERY
+    // lane (noise maps: 4096 candidate pairs per limb, almost all of which fail within the first samples; each sample is 2 x 16-tap bicubic
+    // evaluations per scale).  Survivors have run all 10 samples in the reference's order: the same sum, the same count.  (The range check of
+    // the sample coordinates — `bad`, the reference's CHECK — covered all 10 above and does not depend on this loop.)
     float sum = 0;
     int count = 0;
+    const int allowed_fail = num_inter - (p.inter_min_above + 1);   // COCO: 0 (all 10 must pass), MPI: 1
+    bool alive = true;
 #pragma unroll
     for (int lm = 0; lm < num_inter; lm++) {
-      const float score = (vec_x * px[lm] + vec_y * py[lm]);
+      if (!p.pairs_full && !__any(alive)) break;   // wave-uniform
+      float pxl, pyl;
+      if (FUSED) {  // the two PAF samples straight from the low-res maps (no resized map in memory)
+        const int my = idxs[lm] / NW, mx = idxs[lm] - my * NW;
+        if (stage) resized_pair(geo, r.num, lmap, lmap + r.num * lplane, lplane, my, mx, &pxl, &pyl);
+        else resized_pair(geo, r.num, r.src + (long)mapIdx[2 * k] * lplane, r.src + (long)mapIdx[2 * k + 1] * lplane, (long)r.C * lplane, my, mx, &pxl, &pyl);
+      } else {
+        pxl = map_x[idxs[lm]];
+        pyl = map_y[idxs[lm]];
+      }
+      const float score = (vec_x * pxl + vec_y * pyl);
       if (score > p.inter_threshold) {
         sum = sum + score;
         count++;
       }
+      if (lm + 1 - count > allowed_fail) alive = false;   // (NaN scores fail the compare like in the reference and count as failed)
     }
     if (bad) *p.num_people = CONNECT_ERR_RANGE;  // the reference CHECK-fails here (rtpose.cpp:928)
     else if (count > p.inter_min_above) {
