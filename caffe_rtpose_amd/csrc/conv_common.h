@@ -103,8 +103,20 @@ __device__ __forceinline__ void conv_store_dst(const ConvDst dd, int Cout, long 
 #endif
         ((uint4*)dp)[u] = pk;
       }
-    } else {
-      for (int u = 0; u < nvalid; ++u) dp[u] = out[u];
+    } else {   // a partial chunk (the last channels of a 38- / 19-channel branch output) or an unaligned slice: as few stores as the alignment allows
+      // (unrolled with constant indices and run-time predicates: a run-time index would put out[] into scratch memory)
+      int done = 0;
+      if constexpr (sizeof(T) == 2) {
+        if ((((size_t)dp) & 3) == 0) {
+#pragma unroll
+          for (int u = 0; u < 16; u += 2)
+            if (u + 2 <= nvalid) { unsigned w; __builtin_memcpy(&w, &out[u], 4); *(unsigned*)(dp + u) = w; }
+          done = nvalid & ~1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u >= done && u < nvalid) dp[u] = out[u];
     }
     if (dd.lo_off) {  // split-precision consumer: the rounding error of the stored value, as a second T
       T lo[16];
@@ -119,7 +131,9 @@ __device__ __forceinline__ void conv_store_dst(const ConvDst dd, int Cout, long 
           ((uint4*)lp)[u] = pk;
         }
       } else {
-        for (int u = 0; u < nvalid; ++u) lp[u] = lo[u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (u < nvalid) lp[u] = lo[u];
       }
     }
     if constexpr (sizeof(T) == 2) {
@@ -148,12 +162,26 @@ __device__ __forceinline__ void conv_store_dst(const ConvDst dd, int Cout, long 
           *(uint2*)qb = l0; *(uint2*)(qb + 8) = l1;
           *(uint2*)(qb + 64) = h0; *(uint2*)(qb + 72) = h1;
         } else {
-          for (int u = 0; u < nvalid; ++u) {
-            const int cu = ch + u;
-            unsigned char* qb = qrow + (cu >> 6) * 128 + (cu & 63);
-            qb[0] = (unsigned char)(pack4_fp8(lof[u], 0.f, 0.f, 0.f) & 0xff);
-            qb[64] = (unsigned char)(pack4_fp8(hif[u], 0.f, 0.f, 0.f) & 0xff);
+          int qdone = 0;
+          if ((ch & 3) == 0) {   // 4 channels = 4 bytes of one 64-channel q group (a group boundary is a multiple of 4)
+#pragma unroll
+            for (int u = 0; u < 16; u += 4)
+              if (u + 4 <= nvalid) {
+                const int cu = ch + u;
+                unsigned char* qb = qrow + (cu >> 6) * 128 + (cu & 63);
+                *(unsigned*)qb = pack4_fp8(lof[u], lof[u + 1], lof[u + 2], lof[u + 3]);
+                *(unsigned*)(qb + 64) = pack4_fp8(hif[u], hif[u + 1], hif[u + 2], hif[u + 3]);
+              }
+            qdone = nvalid & ~3;
           }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (u >= qdone && u < nvalid) {
+              const int cu = ch + u;
+              unsigned char* qb = qrow + (cu >> 6) * 128 + (cu & 63);
+              qb[0] = (unsigned char)(pack4_fp8(lof[u], 0.f, 0.f, 0.f) & 0xff);
+              qb[64] = (unsigned char)(pack4_fp8(hif[u], 0.f, 0.f, 0.f) & 0xff);
+            }
         }
       }
     }
@@ -277,7 +305,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& P, const ConvPro
     if (out_nchw) {
       float* op = out_nchw + (((long)img * pr.out_C + pr.out_coff + c0) * P.H + y) * P.W + (xp - P.halo);
       const long plane = (long)P.H * P.W;
-      for (int u = 0; u < nvalid; ++u) op[u * plane] = v[u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u < nvalid) op[u * plane] = v[u];
     }
   }
 }
