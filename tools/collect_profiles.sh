@@ -7,8 +7,10 @@ O=$R/gpurun_out/profiles
 P=${1:-mixed}          # precision mode of the headline line (bench.py default)
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 400 python $R/bench.py --precision $P > $O/bench_${P}_n1.json 2> $O/bench_${P}_n1.err
-tail -c 400 $O/bench_${P}_n1.json
+timeout 600 python $R/bench.py --precision $P > $O/bench_${P}_n1.json 2> $O/bench_${P}_n1.err
+cp $R/bench_detail.json $O/bench_detail_${P}_n1.json 2>/dev/null
+echo "bench line: $(wc -c < $O/bench_${P}_n1.json) bytes"; tail -c 400 $O/bench_${P}_n1.json
+( cd $R && timeout 120 python tools/stamp_timeline.py host 2 7 800 2>&1 | grep -v amdgpu.ids ) > $O/stamp_timeline.txt
 rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --precision $P --no_cpu_baseline --no_sub_results --no_parity > $O/bench_${P}_n1_under_rocprof.json 2> /tmp/kt.err
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_${P}_n1_kernel_stats.csv
 python $R/tools/timeline.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) > $O/bench_${P}_n1_timeline.txt 2>&1

@@ -3,7 +3,7 @@ cd ${GRAFT_REPO_ROOT:-$PWD}   # round-end evidence on the GPU box: GPU tests (wi
 O=gpurun_out/final; mkdir -p $O
 timeout 2400 python -m pytest tests -q -s -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
-( echo "# python tools/prof_steps.py 2 1 mixed -v   (every plan step alone on the chip, 30 repetitions; final round-5 state)"; timeout 200 python tools/prof_steps.py 2 1 mixed -v
+( echo "# python tools/prof_steps.py 2 1 mixed -v   (every plan step alone on the chip, 30 repetitions; final round-6 state)"; timeout 200 python tools/prof_steps.py 2 1 mixed -v
   echo; echo "# python tools/prof_steps.py 2 1 fp16"; timeout 200 python tools/prof_steps.py 2 1 fp16
   echo; echo "# python tools/prof_steps.py 1 3 mixed"; timeout 200 python tools/prof_steps.py 1 3 mixed ) 2>&1 | grep -v amdgpu.ids > $O/steps.txt
 head -3 $O/steps.txt
