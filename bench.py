@@ -731,9 +731,9 @@ def main():
     ap.add_argument("--devices", default=None, help="device of every rank, e.g. 0,0: lets N ranks share one GPU (a test hook like rtpose.bin --devices; default: rank i uses device LOCAL_RANK)")
     ap.add_argument("--broadcast_weights", action="store_true", help="N > 1: rank 0's packed weight arena is broadcast to the other ranks (rtp_weight_blob_export / import) "
                     "instead of every rank keeping the copy it packed itself; one-time, outside the timed region")
-    ap.add_argument("--hw_queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this process (set before the first HIP call unless the environment already has it). "
-                    "Default: 6 for batches of 2 (the engine's ten streams then put every conv stack on a hardware queue of its own: +6 %% frames/s), the runtime's 4 "
-                    "otherwise (batches of 5 lose 25 %% on 6) — a measured setting like --in_flight (profiles/r06_experiments.txt)")
+    ap.add_argument("--hw_queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (set before the first HIP call unless the environment already has it): "
+                    "with at least as many hardware queues as batch contexts the engine gives every context one stream and so one queue to itself "
+                    "(+12 %% frames/s at batches of 2 against the runtime's default 4; engine.cpp 'hardware queues', profiles/r06_experiments.txt)")
     ap.add_argument("--detail_out", default=None, help="(internal) write the detail JSON to this path only: how the parent run collects a leg it started as a subprocess")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_sub_results", action="store_true")
@@ -745,11 +745,9 @@ def main():
     global DETAIL_OUT, USER_HW_QUEUES
     DETAIL_OUT = args.detail_out
     USER_HW_QUEUES = os.environ.get("GPU_MAX_HW_QUEUES")       # a value from the caller's environment wins, here and in the legs
-    if args.hw_queues is None:
-        args.hw_queues = 6 if args.batch_frames == 2 else 4
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))   # (the HIP runtime reads it once, at its first call: torch and the engine are imported below)
     if args.in_flight is None:
-        table = {("mpi", 5): 10, ("coco", 2): 7 if args.num_scales == 1 else 6, ("coco", 1): 7 if args.num_scales == 1 else 3}   # measured optima (profiles/r03_in_flight.txt)
+        table = {("mpi", 5): 15, ("coco", 2): 7 if args.num_scales == 1 else 6, ("coco", 1): 7 if args.num_scales == 1 else 3}   # measured optima (profiles/r03_in_flight.txt)
         args.in_flight = max(table.get((args.model, args.batch_frames), 2 * args.batch_frames), args.batch_frames)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -1457,14 +1457,19 @@ int enqueue_frame(rtp_engine* e, Ctx& cx, const float* input_dev, bool materiali
 // ---- hardware queues ------------------------------------------------------------------------------------------------------------------
 // A hardware queue runs the kernels of ITS streams one after the other, and the HIP runtime attaches every new stream to the queue with the
 // fewest streams (tools/hwq_probe.hip: the first Q streams take queues 0..Q-1, later ones Q-1, Q-2, .., 0, Q-1, ..; Q = GPU_MAX_HW_QUEUES,
-// default 4, read once at the process's first HIP call).  A batch context creates its conv stream, then one stream per further frame of the
-// batch; with batches of 2 and 5 contexts that is 10 streams.  On 4 queues every conv stack shares its queue with another context's
-// conv stack or chain; on 6 queues the five conv stacks sit on five different queues, each shared with ONE other context's frame-1 chain:
-// +6 % frames/s (1087 -> 1154, same box, three repetitions; profiles/r06_experiments.txt).  Dealing streams to explicit conv / post queue
-// classes (conv stacks alone on their queues) measured WORSE (900 against 1067), as round 5's RTP_STREAM_PLAN did: a chain that waits for
-// nothing but its own batch holds CUs exactly when the next batch's stack wants them.  The host programs therefore only choose the queue
-// COUNT per workload (bench.py --hw_queues, rtpose.bin: 6 for batches of 2, the runtime's 4 otherwise — batches of 5 lose 25 % on 6), the
-// engine keeps its creation order.
+// default 4, read once at the process's first HIP call).  Rounds 1-5 gave every frame of a batch beyond the first a post-processing stream of
+// its own; with batches of 2 and five contexts that is ten streams on four queues, and every conv stack shares its queue with another context's
+// stack or chain (head-of-line blocking: a kernel waits behind a kernel of ANOTHER batch although its own inputs are ready).
+// Round 6: when the queues suffice (contexts <= Q), a context has ONE stream — staging, conv stack and the chains of all its frames — and
+// therefore one hardware queue to itself: COCO batches of 2, seven in flight 1071 -> 1203 frames/s on 8 queues (+12 %), MPI batches of 5
+// 1328 -> 1570-1600 (three contexts: the default 4 queues suffice); with too few queues the old arrangement is the better one (1030 against
+// 1068 on 4 queues at batches of 2) and stays.  The host programs raise the count (bench.py --hw_queues, rtpose.bin: GPU_MAX_HW_QUEUES=8 before
+// their first HIP call unless the environment has it; a library cannot: the runtime reads it once).  profiles/r06_experiments.txt section 6.
+int hw_queue_count() {
+  const char* v = getenv("GPU_MAX_HW_QUEUES");
+  const int q = v ? atoi(v) : 4;
+  return q >= 1 && q <= 64 ? q : 4;
+}
 hipError_t make_stream(hipStream_t* s, bool post) {
 #ifdef RTP_EXPERIMENTS
   if (post) {
@@ -1572,7 +1577,9 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
       cx.slot[j].own_stream = true;
       cx.slot[j].preset_stream = true;
     }
-    if ((rc = alloc_slot(e, cx, cx.slot[j], j == 0 && !(own0 && own0[0] == '1')))) return rc;
+    static const char* shall = RTP_EXP_ENV("RTP_POST_SHARE_ALL");  // experiments: 1 / 0 = every frame's chain on the batch's conv stream (one stream per context) / round 5's streams
+    const bool one_stream = shall ? shall[0] == '1' : (int)e->ctx.size() <= hw_queue_count();   // one hardware queue per context when the queues suffice (see "hardware queues" above)
+    if ((rc = alloc_slot(e, cx, cx.slot[j], (j == 0 && !(own0 && own0[0] == '1')) || one_stream))) return rc;
   }
   {
     // HIP deals its hardware queues to streams round-robin in creation order (4 queues).  A context owns batch_frames streams (its conv
