@@ -8,6 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import importlib.util
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # like bench.py and rtpose.bin: one hardware queue per batch context (engine.cpp "hardware queues")
 import numpy as np
 import caffe_rtpose_amd as r
 
