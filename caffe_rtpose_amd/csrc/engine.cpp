@@ -1579,6 +1579,12 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
     }
     static const char* shall = RTP_EXP_ENV("RTP_POST_SHARE_ALL");  // experiments: 1 / 0 = every frame's chain on the batch's conv stream (one stream per context) / round 5's streams
     const bool one_stream = shall ? shall[0] == '1' : (int)e->ctx.size() <= hw_queue_count();   // one hardware queue per context when the queues suffice (see "hardware queues" above)
+    if (!one_stream && !shall && j == 1) {   // once per process: the setting a host program can make and a library cannot
+      static std::atomic<bool> hinted{false};
+      if (!hinted.exchange(true))
+        fprintf(stderr, "rtpose-mi355x: %zu batch contexts on %d HIP hardware queues: with GPU_MAX_HW_QUEUES >= %zu in the environment before the process's first "
+                        "HIP call every context gets a queue to itself (+10 %% frames/s at batches of 2; INTEGRATION.md)\n", e->ctx.size(), hw_queue_count(), e->ctx.size());
+    }
     if ((rc = alloc_slot(e, cx, cx.slot[j], (j == 0 && !(own0 && own0[0] == '1')) || one_stream))) return rc;
   }
   {
