@@ -2825,6 +2825,10 @@ static long plan_summary_impl(const rtp_config* cfg, char* buf, size_t buflen) {
   for (int l = 0; l < e->nlevels; ++l)
     o << "level " << l << " H " << e->geom[l].H << " W " << e->geom[l].W << " halo " << e->geom[l].halo << "\n";
   o << "arena_bytes " << e->arena_bytes << " weights_bytes " << e->weights_bytes << " tensors " << e->tensors.size() << "\n";
+  {  // which streams a batch context gets (alloc_ctx; "hardware queues" above): one for everything when the runtime's hardware queues suffice
+    const int nctx = (e->cfg.frames_in_flight + e->B - 1) / e->B + (e->B > 1 ? 1 : 0);
+    o << "streams contexts " << nctx << " hw_queues " << hw_queue_count() << " arrangement " << ((nctx <= hw_queue_count() || e->B == 1) ? "one_per_context" : "per_frame_chains") << "\n";
+  }
   double gflop = 0, mfma_gflop = 0;
   for (auto& s : e->steps) {
     if (s.type == 0) o << "step pack\n";

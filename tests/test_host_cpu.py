@@ -510,3 +510,23 @@ def test_eighth_resolution_launches_leave_cus_free():
         assert wgs == 248 or (wgs == 124 and " tile 128x128 " in ln), ln
     dom = [ln for ln in low if " k 7 cin_p 128 " in ln]
     assert len(dom) == 20 and all("wgs 248" in ln and " tile 128x64 " in ln for ln in dom)   # the dominant shape keeps full-chip launches
+
+
+def test_stream_arrangement_follows_the_hardware_queue_count(monkeypatch):
+    """engine.cpp 'hardware queues': a batch context gets ONE stream (staging, conv stack, every frame's post-processing chain) when the HIP
+    runtime has at least as many hardware queues (GPU_MAX_HW_QUEUES, default 4) as there are contexts, the per-frame chain streams of rounds 1-5
+    otherwise; bench.py and rtpose.bin raise the count to 8 (round 6: +9..12 % frames/s at batches of 2)."""
+    def arrangement(**kw):
+        ln = [l for l in _plan_lines(**kw) if l.startswith("streams ")]
+        assert len(ln) == 1
+        w = ln[0].split()
+        return int(w[2]), int(w[4]), w[6]
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert arrangement(batch_frames=2, frames_in_flight=7) == (5, 4, "per_frame_chains")       # five contexts on the runtime's four queues
+    assert arrangement(batch_frames=2, frames_in_flight=5) == (4, 4, "one_per_context")
+    assert arrangement(model=1, net_w=496, net_h=368, batch_frames=5, frames_in_flight=15) == (4, 4, "one_per_context")
+    assert arrangement(batch_frames=1, frames_in_flight=3)[2] == "one_per_context"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert arrangement(batch_frames=2, frames_in_flight=7) == (5, 8, "one_per_context")
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "0")                                                   # nonsense falls back to the default
+    assert arrangement(batch_frames=2, frames_in_flight=7)[1] == 4
