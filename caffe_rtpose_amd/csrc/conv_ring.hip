@@ -213,6 +213,18 @@ constexpr int ring_wait_count(int s) {
   return n;
 }
 
+// The LAST strip of a tile issues nothing that does not exist (no strip for a filter row behind the last one, no weight tile behind tile
+// T-1): what is younger than tile P shrinks to the tiles that are left, min(SB-2, KS-1-s), and the last tap waits for vmcnt(0) — every DMA
+// has landed when the K loop ends.  (Rounds 2-5 issued dummy re-loads through the tail so that one formula served every step; the DMA waves then
+// had to wait for those dummies — a trip to L2 / memory issued one tap earlier — before the barrier that lets the consumers start the epilogue.)
+template <int KS, int SB, int B_PW>
+constexpr int ring_wait_last(int s) {
+  const int left = KS - 1 - s;
+  int n = (left < SB - 2 ? left : SB - 2) * B_PW;
+  if (s == 0 && KS * B_PW < n) n = KS * B_PW;
+  return n;
+}
+
 // SPEC = wave specialisation: 8 waves, one producer + one consumer per SIMD.  Waves 4..7 only issue
 // the LDS-DMA (and wait for it, counted); waves 0..3 only ds_read + MFMA (+ the epilogue).  The
 // in-order VMEM issue of a wave (~50 cycles per 1 KiB piece, 3-5 pieces per tap) then no longer sits
@@ -400,40 +412,54 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, MINW) void conv_ring_kernel(ConvP
       wait_vmcnt<(SB - 1) * B_PW + A_PW>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      auto pstep = [&](auto s_tag, auto first_tag) __attribute__((always_inline)) {
+      auto pstep = [&](auto s_tag, auto first_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr int s = decltype(s_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;   // the tile's last strip: see ring_wait_last
         if constexpr (VAR != 15 && VAR != 16 && VAR != 17) {
-          wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
+          if constexpr (LAST) wait_vmcnt<ring_wait_last<KS, SB, B_PW>(s)>();
+          else wait_vmcnt<ring_wait_count<KS, SB, FIRST, B_PW, A_PW>(s)>();
           __builtin_amdgcn_s_barrier();
         }
         asm volatile("" ::: "memory");
         if constexpr (VAR != 13) {
-          if constexpr (s == 0) { abuf ^= 1; issue_a(abuf ^ 1); }
-          issue_b(ist);
+          if constexpr (s == 0 && !LAST) { abuf ^= 1; issue_a(abuf ^ 1); }
+          if constexpr (!LAST || s + SB - 1 <= KS - 1) issue_b(ist);
         }
         ist = (ist + 1 == SB) ? 0 : ist + 1;
       };
-      pstep(std::integral_constant<int, 1>{}, std::true_type{});
-      pstep(std::integral_constant<int, 2>{}, std::true_type{});
+      const std::false_type NL{};
+      const std::true_type LS{};
+      pstep(std::integral_constant<int, 1>{}, std::true_type{}, NL);
+      pstep(std::integral_constant<int, 2>{}, std::true_type{}, NL);
       if constexpr (KS == 7) {
-        pstep(std::integral_constant<int, 3>{}, std::true_type{});
-        pstep(std::integral_constant<int, 4>{}, std::true_type{});
-        pstep(std::integral_constant<int, 5>{}, std::true_type{});
-        pstep(std::integral_constant<int, 6>{}, std::true_type{});
+        pstep(std::integral_constant<int, 3>{}, std::true_type{}, NL);
+        pstep(std::integral_constant<int, 4>{}, std::true_type{}, NL);
+        pstep(std::integral_constant<int, 5>{}, std::true_type{}, NL);
+        pstep(std::integral_constant<int, 6>{}, std::true_type{}, NL);
       }
-      for (int sc = 1; sc < nstrips; ++sc) {
-        pstep(std::integral_constant<int, 0>{}, std::false_type{});
-        pstep(std::integral_constant<int, 1>{}, std::false_type{});
-        pstep(std::integral_constant<int, 2>{}, std::false_type{});
+      for (int sc = 1; sc < nstrips - 1; ++sc) {
+        pstep(std::integral_constant<int, 0>{}, std::false_type{}, NL);
+        pstep(std::integral_constant<int, 1>{}, std::false_type{}, NL);
+        pstep(std::integral_constant<int, 2>{}, std::false_type{}, NL);
         if constexpr (KS == 7) {
-          pstep(std::integral_constant<int, 3>{}, std::false_type{});
-          pstep(std::integral_constant<int, 4>{}, std::false_type{});
-          pstep(std::integral_constant<int, 5>{}, std::false_type{});
-          pstep(std::integral_constant<int, 6>{}, std::false_type{});
+          pstep(std::integral_constant<int, 3>{}, std::false_type{}, NL);
+          pstep(std::integral_constant<int, 4>{}, std::false_type{}, NL);
+          pstep(std::integral_constant<int, 5>{}, std::false_type{}, NL);
+          pstep(std::integral_constant<int, 6>{}, std::false_type{}, NL);
         }
       }
-      wait_vmcnt<0>();  // the dummy tail DMAs have landed before LDS is reused by the epilogue
+      // the last strip (nstrips = KS * chunks >= 3: never the first one): only what exists is issued, the last tap's wait is vmcnt(0)
+      pstep(std::integral_constant<int, 0>{}, std::false_type{}, LS);
+      pstep(std::integral_constant<int, 1>{}, std::false_type{}, LS);
+      pstep(std::integral_constant<int, 2>{}, std::false_type{}, LS);
+      if constexpr (KS == 7) {
+        pstep(std::integral_constant<int, 3>{}, std::false_type{}, LS);
+        pstep(std::integral_constant<int, 4>{}, std::false_type{}, LS);
+        pstep(std::integral_constant<int, 5>{}, std::false_type{}, LS);
+        pstep(std::integral_constant<int, 6>{}, std::false_type{}, LS);
+      }
+      wait_vmcnt<0>();  // (nothing is in flight any more: the last tap waited for everything)
       __builtin_amdgcn_s_barrier();
       // the DMA waves stay for the epilogue: they take half of the (pixel, 16-channel chunk) items of the staged tile (dump = false)
       if constexpr (POOL) conv_epilogue_pool<T, BM, BN, WM, WN, KSPLIT, TM, TN, 512>(P, pr, acc, smem, kg, wm0, wn0, lane, img, pool_pair, pool_x0, n0, false);
