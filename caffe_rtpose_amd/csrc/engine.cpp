@@ -1555,6 +1555,17 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
     cx.spare_stream = q[(ci & 1) ^ 1];
     planned_streams = {q[2], q[3]};
   } else
+#ifdef RTP_EXPERIMENTS
+  if (const char* cm = getenv("RTP_CTX_CUMASK")) {   // experiments: 2 = contexts alternate between two halves of the chip (16 CUs of every XCD each), 3 = three thirds
+    const int parts = atoi(cm), ci = (int)(&cx - &e->ctx[0]);
+    if (parts >= 2 && parts <= 4) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int per = 32 / parts, lo = (ci % parts) * per;           // CU index inside an XCD = bit / 8 (the KFD interleaves the mask bits over the XCDs)
+      for (int b = 0; b < 256; ++b) if ((b >> 3) >= lo && (b >> 3) < lo + per) mask[b >> 5] |= 1u << (b & 31);
+      HIPCHK(e, hipExtStreamCreateWithCUMask(&cx.stream, 8, mask));
+    } else HIPCHK(e, make_stream(&cx.stream, false));
+  } else
+#endif
   HIPCHK(e, make_stream(&cx.stream, false));
   HIPCHK(e, hipMalloc((void**)&cx.arena, e->arena_bytes));
   HIPCHK(e, hipMemset(cx.arena, 0, e->arena_bytes));
