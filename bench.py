@@ -886,7 +886,11 @@ def main():
                 eng.submit_device(frames[(b * nb + j) % len(frames)], tag=b * nb + j)
             for j in range(nb):
                 eng.collect()
+            if b % 8 == 7:
+                eng.kernel_timing(-1)   # idle here: fold the event pairs into the totals so the table of pairs never fills
         dom_ms, dom_n, dom_flops = eng.kernel_timing(-1)
+        if eng.probe_dropped()["timing_pairs"]:
+            raise RuntimeError(f"roofline pass truncated: {eng.probe_dropped()} launches were not timed (rtp_probe_dropped)")
         byp = eng.kernel_timing_by_passes()
         steps_t = eng.kernel_timing_steps()
         eng.kernel_timing(0)
@@ -955,6 +959,9 @@ def main():
             eng.busy_probe(1)
             mb = measure(eng, submit, 200, 20, args.in_flight, 0.5)
             busy = busy_account(eng.busy_probe(-1))
+            dropped = eng.probe_dropped()
+            if busy and (dropped["busy_spans"] or dropped["busy_graph_frames"]):
+                busy["truncated"] = dropped
             eng.busy_probe(0)
             if busy:
                 busy["frames_per_s_with_probe"] = mb["fps"] * (1 if world == 1 else 1.0 / world)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "rtp_kernel_timing_by_passes": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "rtp_kernel_timing_steps": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
     "rtp_busy_probe": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "rtp_probe_dropped": (C.c_int, [vp, C.POINTER(C.c_long)]),
     "rtp_stamp_probe": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "rtp_submit": (C.c_int, [vp, fp, C.c_uint64]),
     "rtp_submit_device": (C.c_int, [vp, vp, C.c_uint64]),

@@ -237,6 +237,7 @@ struct rtp_engine {
   std::vector<double> step_ms;            // per plan step: event-timed milliseconds / launches of the timing pass (rtp_kernel_timing_steps)
   std::vector<long> step_n;
   int tev_next = 0;
+  long probe_dropped[3] = {0, 0, 0};      // rtp_probe_dropped: timing pairs not recorded (table full), busy spans dropped (cap), graph-replayed batches the busy probe skipped
   static const int TEV_PAIRS = 4096;
   // device-side pre-processing (row a1)
   const short* warp_tab_dev = nullptr;  // inside prep_tables
@@ -1226,7 +1227,9 @@ int run_frame_stack(rtp_engine* e, Ctx& cx, const float* input_dev, int nimg, bo
     const Step& s = e->steps[si];
     // timing pass: an event pair on this stream around the launch (full batches only: the FLOP count reported is the full batch's);
     // the dominant class only (rtp_kernel_timing 1 / 2) or every step of the plan (3: bench.py's roofline.classes)
-    const bool timed = e->time_dominant && !cap && nimg == e->NI && (e->time_all || is_dominant_class(e, s)) && e->tev_next < (int)e->tev.size() / 2;
+    const bool want_timed = e->time_dominant && !cap && nimg == e->NI && (e->time_all || is_dominant_class(e, s));
+    const bool timed = want_timed && e->tev_next < (int)e->tev.size() / 2;
+    if (want_timed && !timed) e->probe_dropped[0]++;
     if (timed) HIPCHK(e, hipEventRecord(e->tev[2 * (size_t)e->tev_next], cx.stream));
     struct Close {   // second event + bookkeeping on every way out of the step's branch
       rtp_engine* e; Ctx& cx; const Step& s; size_t si; bool timed;
@@ -2377,6 +2380,8 @@ static int collect_impl(rtp_engine* e, uint64_t* tag, float* joints, int* num_pe
   memcpy(&n, sl.host_out, sizeof(int));
   if (tag) *tag = sl.tag;
   stage_ms(e, cx, sl);
+  if (e->busy_probe && e->busy_base && cx.graph_run) e->probe_dropped[2]++;
+  if (e->busy_probe && e->busy_base && !cx.graph_run && e->busy_spans.size() >= 3 * 65536) e->probe_dropped[1]++;
   if (e->busy_probe && e->busy_base && !cx.graph_run && e->busy_spans.size() < 3 * 65536) {
     float t0 = 0.f, t1 = 0.f;
     if (sj == 0 && cx.stage0_set && hipEventElapsedTime(&t0, e->busy_base, cx.ev_stage0) == hipSuccess &&
@@ -3013,6 +3018,15 @@ int rtp_stamp_probe(rtp_engine* e, int enable, float* spans, int cap) {
   const int n = (int)(e->stamp_spans.size() / 3);
   if (spans) memcpy(spans, e->stamp_spans.data(), sizeof(float) * 3 * (size_t)std::min(n, std::max(cap, 0)));
   return n;
+}
+
+// What the measurement probes could NOT record since engine creation: out[0] = launches rtp_kernel_timing wanted to time after its event
+// table (TEV_PAIRS pairs between two harvests) was full, out[1] = frames whose rtp_busy_probe spans were dropped at the 65536-triple cap,
+// out[2] = frames the busy probe skipped because their batch was a whole-batch graph replay (no per-frame events exist there).
+int rtp_probe_dropped(const rtp_engine* e, long out[3]) {
+  if (!e || !out) return RTP_EINVAL;
+  for (int i = 0; i < 3; ++i) out[i] = e->probe_dropped[i];
+  return RTP_OK;
 }
 
 // Per-step totals of a timing pass switched on with rtp_kernel_timing(e, 3, ..): ms[i] / launches[i] for plan step i (the order of

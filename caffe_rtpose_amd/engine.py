@@ -557,6 +557,12 @@ class Engine:
             lib.rtp_busy_probe(self.h, -1, _f(out), n)
         return out
 
+    def probe_dropped(self):
+        """rtp_probe_dropped: {timing_pairs, busy_spans, busy_graph_frames} the probes could not record since creation."""
+        out = (C.c_long * 3)()
+        self._chk(lib.rtp_probe_dropped(self.h, out))
+        return {"timing_pairs": out[0], "busy_spans": out[1], "busy_graph_frames": out[2]}
+
     def stamp_probe(self, enable=-1):
         """rtp_stamp_probe: kernel residency spans as an [n][3] float32 array {slot, start_us, end_us} (device-side wall-clock stamps)."""
         n = lib.rtp_stamp_probe(self.h, enable, None, 0)

@@ -356,6 +356,11 @@ int rtp_kernel_timing_steps(const rtp_engine* e, double* ms, long* launches, int
  * the end of its conv stack; kind 1 = one frame's post-processing chain incl. the D2H of its joints.  Returns the number of triples
  * (at most `cap` are copied to `spans`, which may be NULL). */
 int rtp_busy_probe(rtp_engine* e, int enable, float* spans, int cap);
+/* What the probes above could not record since the engine was created: out[0] = launches rtp_kernel_timing wanted to time while its table
+ * of event pairs (4096 between two harvests) was full, out[1] = frames whose rtp_busy_probe spans fell beyond its 65536-triple cap,
+ * out[2] = frames the busy probe skipped because their batch ran as one whole-batch graph replay (no per-frame events there).  A
+ * measurement that reads non-zero counts here is truncated and must say so (bench.py refuses to print a roofline from it). */
+int rtp_probe_dropped(const rtp_engine* e, long out[3]);
 /* Kernel RESIDENCY without a profiler: while on, thread 0 of every workgroup of every kernel of the per-frame path (device pre-processing,
  * conv stack, ImResize+Nms, connect) folds the chip's 100 MHz wall clock into a per-launch slot — first workgroup start, last workgroup
  * end.  enable = 1: on + reset (idle engine only; the batch graphs are re-captured with the slots), 0: off, -1: harvest + read.  spans:

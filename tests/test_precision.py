@@ -299,6 +299,7 @@ def test_per_step_timing_and_busy_probe_feed_the_bench_line():
     acc = bench.busy_account(spans)
     print(f"[busy] {acc['busy_frac']:.4f} busy, conv streams {acc['conv_streams_busy_frac']:.3f}, {acc['conv_stacks_concurrent_avg']:.2f} stacks in flight, post chains {acc['post_chains_busy_frac']:.3f}")
     assert 0.9 < acc["busy_frac"] <= 1.0 and acc["conv_stacks_concurrent_avg"] > 1.0
+    assert e.probe_dropped() == {"timing_pairs": 0, "busy_spans": 0, "busy_graph_frames": 0}   # nothing above was truncated (rtp_probe_dropped)
     e.submit(x, tag=1)
     with pytest.raises(r.RtpError):       # idle engines only
         e.busy_probe(1)
