@@ -16,6 +16,7 @@ lib = C.CDLL(LIB_PATH)
 
 class rtp_config(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint),
         ("device_id", C.c_int),
         ("model", C.c_int),
         ("proto_path", C.c_char_p),

@@ -1971,6 +1971,7 @@ extern "C" {
 int rtp_config_default(rtp_config* cfg) {
   if (!cfg) return RTP_EINVAL;
   memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = (unsigned)sizeof *cfg;
   cfg->device_id = 0;
   cfg->model = RTP_MODEL_COCO_18;
   cfg->proto_path = nullptr;
@@ -3474,7 +3475,17 @@ int rtp_copy_weights_from(rtp_engine* dst, rtp_engine* src) {
 }
 
 // Nothing may unwind through the C boundary: allocation failures while building a plan come back as codes.
+// A caller compiled against another version of the header (or one that never called rtp_config_default) hands over a struct of another
+// layout: refuse it instead of reading fields that are not there.
+static int config_layout_ok(const rtp_config* cfg) {
+  if (cfg && cfg->struct_size != (unsigned)sizeof(rtp_config))
+    return fail(nullptr, RTP_EINVAL, "rtp_config.struct_size is %u, this library's rtp_config has %u bytes: fill the struct with rtp_config_default() of the "
+                "header this library was built from (include/rtpose_mi355x.h) and recompile the caller", cfg->struct_size, (unsigned)sizeof(rtp_config));
+  return RTP_OK;
+}
+
 int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
+  if (int rc = config_layout_ok(cfg)) return rc;
   try {
     return engine_create_impl(cfg, out);
   } catch (const std::bad_alloc&) {
@@ -3484,6 +3495,7 @@ int rtp_engine_create(const rtp_config* cfg, rtp_engine** out) {
   }
 }
 long rtp_plan_summary(const rtp_config* cfg, char* buf, size_t buflen) {
+  if (int rc = config_layout_ok(cfg)) return rc;
   try {
     return plan_summary_impl(cfg, buf, buflen);
   } catch (const std::exception& ex) {

@@ -64,6 +64,10 @@ typedef struct rtp_engine rtp_engine;
 
 /* Replaces: flags + warmup() state (rtpose.cpp:50-72, 173-237). */
 typedef struct rtp_config {
+  unsigned int struct_size;/* sizeof(rtp_config) of the header rtp_config_default was COMPILED against (it writes  *
+                            * it).  rtp_engine_create / rtp_plan_summary return RTP_EINVAL for any other value: a    *
+                            * caller built against another version of this header (fields were appended in rounds     *
+                            * 2-5) or one that skipped rtp_config_default is refused instead of being misread.        */
   int device_id;           /* --start_device + worker index (rtpose.cpp:1466)                     */
   int model;               /* RTP_MODEL_*; ignored when proto_path is given                        */
   const char* proto_path;  /* --caffeproto deploy prototxt, or NULL = built-in linevec net         */
@@ -120,7 +124,8 @@ typedef struct rtp_config {
 } rtp_config;
 
 /* Fill cfg with the reference's flag defaults (rtpose.cpp:50-72): COCO, 656x368, 1 scale,
- * start_scale 1, scale_gap 0.3, 1280x720, RTP_PREC_MIXED, 2 frames in flight, graph replay. */
+ * start_scale 1, scale_gap 0.3, 1280x720, RTP_PREC_MIXED, 2 frames in flight, graph replay — and
+ * struct_size.  Every rtp_config must start here. */
 int rtp_config_default(rtp_config* cfg);
 
 /* Replaces: new Net<float>(proto, TEST) + CopyTrainedLayersFrom + Reshape + dry run

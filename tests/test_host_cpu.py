@@ -530,3 +530,25 @@ def test_stream_arrangement_follows_the_hardware_queue_count(monkeypatch):
     assert arrangement(batch_frames=2, frames_in_flight=7) == (5, 8, "one_per_context")
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "0")                                                   # nonsense falls back to the default
     assert arrangement(batch_frames=2, frames_in_flight=7)[1] == 4
+
+
+def test_a_config_of_another_header_version_is_refused():
+    """include/rtpose_mi355x.h rtp_config.struct_size: rtp_config_default writes the size of the library's struct; rtp_plan_summary and
+    rtp_engine_create refuse any other value (a caller compiled against another header version, or one that skipped rtp_config_default)
+    with RTP_EINVAL and both sizes in rtp_last_error(NULL), before anything else is read.  The reference's counterpart is a gflags parse
+    (rtpose.cpp:50-72): there is no struct to get wrong."""
+    import caffe_rtpose_amd as r
+    from caffe_rtpose_amd._lib import lib, rtp_config
+    good = rtp_config()
+    assert lib.rtp_config_default(C.byref(good)) == 0 and good.struct_size == C.sizeof(rtp_config)   # the ctypes mirror has the library's layout
+    buf = C.create_string_buffer(1 << 16)
+    assert lib.rtp_plan_summary(C.byref(good), buf, len(buf)) > 0
+    for bad_size in (0, C.sizeof(rtp_config) - 4, C.sizeof(rtp_config) + 8):
+        bad = rtp_config()
+        lib.rtp_config_default(C.byref(bad))
+        bad.struct_size = bad_size
+        assert lib.rtp_plan_summary(C.byref(bad), buf, len(buf)) == r.RTP_EINVAL
+        msg = lib.rtp_last_error(None).decode()
+        assert f"struct_size is {bad_size}" in msg and str(C.sizeof(rtp_config)) in msg
+        h = C.c_void_p()
+        assert lib.rtp_engine_create(C.byref(bad), C.byref(h)) == r.RTP_EINVAL and not h.value
