@@ -448,6 +448,32 @@ def kernel_classes(plan_lines, layers, step_times, net_w, net_h, images_per_laun
     return out, total
 
 
+def stamp_dominant(spans, plan_lines, flops_per_launch, peak):
+    """The dominant launches seen from the DEVICE: rtp_stamp_probe's {slot, start_us, end_us} triples (slot < 64 = plan step, in the order of
+    rtp_plan_summary's "step" lines) of batches processed one at a time -> for the 7x7 128->128 pair steps the mean residency (first
+    workgroup's start .. last workgroup's end, one wall clock for all XCDs) per MFMA pass count and over all of them.  No launch latency and
+    no event marker inside the span: the quantity a kernel trace reports (profiles/ rocprofv3 stats), measured without a tracer."""
+    import numpy as np
+    dom = {}
+    for i, ln in enumerate(plan_lines):
+        if re.match(r"step conv .* k 7 cin_p 128 cout 128 ", ln):
+            dom[i] = "2" if " passes 2q " in ln else "3" if re.search(r" passes 3\w* ", ln) else "1"
+    acc = {}
+    for slot, t0, t1 in np.asarray(spans, np.float64).reshape(-1, 3):
+        p_ = dom.get(int(slot))
+        if p_ is not None and t1 > t0:
+            a = acc.setdefault(p_, [0, 0.0])
+            a[0] += 1
+            a[1] += t1 - t0
+    n = sum(a[0] for a in acc.values())
+    if not n:
+        return None
+    us = sum(a[1] for a in acc.values()) / n
+    return {"launches": n, "us_per_launch": us, "us_by_mfma_passes": {p_: a[1] / a[0] for p_, a in sorted(acc.items())},
+            "achieved": flops_per_launch / (us * 1e-6) / 1e12, "frac": flops_per_launch / (us * 1e-6) / peak,
+            "what": "device-side residency stamps of the same launches (first workgroup start .. last workgroup end), batches one at a time, no tracer"}
+
+
 def busy_account(spans):
     """rtp_busy_probe's spans -> the share of the wall (first start .. last end, after dropping the first tenth as warm-up) in which the
     engine had work on the GPU: union of every batch's conv-stream span (first input staging .. end of its conv stack) and every frame's
@@ -615,6 +641,9 @@ def compact_line(out, detail_paths=()):
     byp = roof.get("by_mfma_passes") or {}
     if byp:
         r_["us_by_mfma_passes"] = {p: rnd(v["ms_per_launch"] * 1e3, 2) for p, v in byp.items()}
+    if roof.get("device_stamps"):   # the same launches by device-side stamps: [us plain, us compensated, fraction of peak] — what a kernel trace reports
+        ds = roof["device_stamps"]
+        r_["device_stamps"] = {"us_by_mfma_passes": {p_: rnd(v, 2) for p_, v in ds["us_by_mfma_passes"].items()}, "frac": rnd(ds["frac"])}
     if roof.get("classes"):
         r_["classes"] = {k: [v["steps_per_batch"], round(v["us_per_launch"], 1), round(v["tflops"])] for k, v in roof["classes"].items()}
         r_["classes_columns"] = "launches per batch, us per launch, algorithmic TFLOP/s"
@@ -904,6 +933,16 @@ def main():
                 classes, total = kernel_classes(plan, eng.conv_layers(), steps_t, eng.net_w, eng.net_h, nb * num_scales, peak)
                 roof["classes"] = classes
                 roof["batch_ms_sum_of_launches"] = total
+            # the same launches once more, seen from the device (cross-check of the event pairs against what a kernel trace reports)
+            eng.stamp_probe(1)
+            for b in range(20):
+                for j in range(nb):
+                    eng.submit_device(frames[(b * nb + j) % len(frames)], tag=b * nb + j)
+                for j in range(nb):
+                    eng.collect()
+            st = eng.stamp_probe(-1)
+            eng.stamp_probe(0)
+            roof["device_stamps"] = stamp_dominant(st, plan, dom_flops, peak)
         except Exception as ex:  # noqa: BLE001
             roof["classes_error"] = str(ex)
         return roof

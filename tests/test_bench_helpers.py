@@ -1,6 +1,7 @@
 """bench.py's host-side bookkeeping that needs no GPU: the per-kernel-class rows of `roofline.classes` (from per-step event timings and
 rtp_plan_summary's step lines) and the union-of-spans account behind `gpu_busy`."""
 import importlib.util
+import json
 import os
 
 import numpy as np
@@ -100,3 +101,26 @@ def test_stamp_account_counts_the_wall_with_no_kernel_resident():
     assert abs(acc["conv_resident_frac"] - 0.80) < 0.01 and abs(acc["post_resident_frac"] - 0.25) < 0.01
     assert abs(acc["kernels_resident_avg"] - 1.05) < 0.02 and abs(acc["kernels_resident_hist"]["2"] - 0.20) < 0.01
     assert b.stamp_account(np.zeros((3, 3), np.float32)) is None
+
+
+def test_stamp_dominant_reads_the_dominant_launches_from_the_device_stamps():
+    """bench.py `roofline.device_stamps`: residency of the 7x7 128->128 pair launches (slot = plan step) per MFMA pass count, and the roofline
+    fraction they give — the tracer-free counterpart of the rocprofv3 kernel stats under profiles/."""
+    b = _bench()
+    plan = ["step first conv1_1 k 3 cin 3 cout 64 relu 1 passes 1 wgs 736",
+            "step conv Mconv1_stage2_L1 + Mconv1_stage2_L2 k 7 cin_p 192 cout 128 coutp 128 relu 1 tile 128x128 rowb 128 passes 1 impl ring wgs 124 dsts 1 lowres 0",
+            "step conv Mconv2_stage2_L1 + Mconv2_stage2_L2 k 7 cin_p 128 cout 128 coutp 128 relu 1 tile 128x64 rowb 256 passes 1 impl ring wgs 248 dsts 1 lowres 0",
+            "step conv Mconv2_stage4_L1 + Mconv2_stage4_L2 k 7 cin_p 128 cout 128 coutp 128 relu 1 tile 128x64 rowb 256 passes 2q impl ring wgs 248 dsts 1 lowres 0",
+            "step pw2 Mconv6_stage2_L1 + Mconv6_stage2_L2 -> Mconv7_stage2_L1 + Mconv7_stage2_L2 k 1 cin_p 128 mid 128 cout 38 passes 3aw/3aw tile 64 wgs 248 lowres 0"]
+    spans = []
+    for i in range(10):
+        t = i * 1000.0
+        spans += [(0, t, t + 30), (1, t + 40, t + 90), (2, t + 100, t + 125), (3, t + 130, t + 175), (4, t + 180, t + 190), (64, t + 200, t + 250)]
+    spans.append((2, 5.0, 5.0))       # an empty stamp pair is skipped
+    d = b.stamp_dominant(np.array(spans, np.float32), plan, 24.225775616e9, 2.5e15)
+    assert d["launches"] == 20 and abs(d["us_by_mfma_passes"]["1"] - 25.0) < 1e-3 and abs(d["us_by_mfma_passes"]["2"] - 45.0) < 1e-3
+    assert abs(d["us_per_launch"] - 35.0) < 1e-3 and abs(d["frac"] - 24.225775616e9 / 35e-6 / 2.5e15) < 1e-6
+    assert b.stamp_dominant(np.zeros((0, 3), np.float32), plan, 1.0, 1.0) is None
+    out = {"metric": "m", "value": 1.0, "roofline": {"frac": 0.2, "device_stamps": d}}
+    line = json.loads(b.compact_line(out))
+    assert line["roofline"]["device_stamps"]["us_by_mfma_passes"] == {"1": 25.0, "2": 45.0} and abs(line["roofline"]["device_stamps"]["frac"] - d["frac"]) < 1e-3
