@@ -275,6 +275,16 @@ struct rtp_engine {
 
 namespace {
 
+// Flags of the engine's events.  sync = the event is waited for (by the host or by another stream) after work whose results the waiter reads;
+// the others only take time stamps between launches.  Experiments build: RTP_EV_NOFENCE=1 creates the time-stamp events of the per-frame path
+// without the system-scope release fence a default event record carries, 2 = every event (measured: no change in the pipelined frame rate;
+// the event pairs of rtp_kernel_timing are always created without it).
+unsigned event_flags(bool sync) {
+  static const char* nf = RTP_EXP_ENV("RTP_EV_NOFENCE");
+  const int lvl = nf ? atoi(nf) : 0;
+  return (lvl >= 2 || (lvl == 1 && !sync)) ? hipEventDisableSystemFence : hipEventDefault;
+}
+
 int fail(rtp_engine* e, int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -1523,7 +1533,7 @@ int alloc_slot(rtp_engine* e, Ctx& cx, Slot& sl, bool share_stream) {
   HIPCHK(e, hipMemset(sl.joints, 0, jfloats * sizeof(float)));
   HIPCHK(e, hipMalloc((void**)&sl.num_people, sizeof(int)));
   HIPCHK(e, hipHostMalloc((void**)&sl.host_out, (jfloats + 4) * sizeof(float), hipHostMallocDefault));
-  for (int i = 0; i < 5; ++i) HIPCHK(e, hipEventCreate(&sl.ev[i]));
+  for (int i = 0; i < 5; ++i) HIPCHK(e, hipEventCreateWithFlags(&sl.ev[i], event_flags(i == 4)));
   // Staging buffers of rtp_submit_frame for frames up to the display size (a video at --resolution, BASELINE configs[1]) and the renderer's
   // buffers are allocated HERE, under the creation lock: the per-frame path then never allocates (and never takes g_sync_mutex) unless a
   // frame is larger than the display image.
@@ -1578,8 +1588,8 @@ int alloc_ctx(rtp_engine* e, Ctx& cx) {
   const size_t low_floats = (size_t)e->NI * e->heat_channels * e->low_h * e->low_w;
   HIPCHK(e, hipMalloc((void**)&cx.lowres, low_floats * sizeof(float)));
   HIPCHK(e, hipMemset(cx.lowres, 0, low_floats * sizeof(float)));
-  for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.ev[i]));
-  for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreate(&cx.gev[i]));
+  for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreateWithFlags(&cx.ev[i], event_flags(i == 1)));
+  for (int i = 0; i < 2; ++i) HIPCHK(e, hipEventCreateWithFlags(&cx.gev[i], event_flags(i == 1)));
   HIPCHK(e, hipMalloc((void**)&cx.stamps, 2 * STAMP_SLOTS * sizeof(unsigned long long)));
   HIPCHK(e, hipMemset(cx.stamps, 0, 2 * STAMP_SLOTS * sizeof(unsigned long long)));
   cx.slot.resize(e->B);
@@ -1870,7 +1880,7 @@ int replan(rtp_engine* e, int mode, const std::string& rules, bool light) {
 }
 
 int busy_mark_stage0(rtp_engine* e, Ctx& cx) {
-  if (!cx.ev_stage0) HIPCHK(e, hipEventCreate(&cx.ev_stage0));
+  if (!cx.ev_stage0) HIPCHK(e, hipEventCreateWithFlags(&cx.ev_stage0, event_flags(false)));
   HIPCHK(e, hipEventRecord(cx.ev_stage0, cx.in_stream));
   cx.stage0_set = true;
   return RTP_OK;
@@ -2948,7 +2958,9 @@ int rtp_kernel_timing(rtp_engine* e, int enable, double* total_ms, long* launche
     if (e->time_dominant) {
       if (e->tev.empty()) {
         e->tev.assign((size_t)2 * rtp_engine::TEV_PAIRS, nullptr);
-        for (hipEvent_t& ev : e->tev) HIPCHK(e, hipEventCreate(&ev));
+        // time stamps only, nothing waits for them: no system-scope release fence in the marker (a default event record writes the L2s back
+        // before it stamps: 1.8 us of every pair that do not belong to the launch; profiles/r06_experiments.txt)
+        for (hipEvent_t& ev : e->tev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
         e->tev_pass.assign(rtp_engine::TEV_PAIRS, 1);
         e->tev_step.assign(rtp_engine::TEV_PAIRS, -1);
       }

@@ -342,7 +342,7 @@ int rtp_bench_dominant_conv(rtp_engine* e, int iters, float* avg_ms, double* flo
  * enable = 1/0 switches it on/off (resetting the totals on a change), 2 = on AND reset, enable < 0 only
  * reads; the mode can only change on an idle engine.  While on, batches are launched eagerly (no graph
  * replay) and each such launch of a FULL batch sits between a HIP event pair recorded on the stream it
- * runs on; the totals are the pairs' elapsed times.  Submit one batch at a time (collect it before the
+ * runs on (events without the system-scope fence: time stamps only); the totals are the pairs' elapsed times.  Submit one batch at a time (collect it before the
  * next) and a pair brackets its launch alone on the chip — what a profiler's kernel trace reports.
  * Call with an idle engine to harvest.  (Round 2 compared wall-clock stamps of workgroups on different
  * XCDs; their clocks are not synchronised on every box.) */
