@@ -69,10 +69,18 @@ __device__ __forceinline__ BlockCoord decode_block(const ConvParams& P, int ntil
   const int q = total >> 3, r = total & 7;
   const int L = P.xcdmap ? ((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j) : lin;
   BlockCoord b;
-  const int mt = L % total_m;
-  const int rest = L / total_m;
-  b.ntile = rest % ntiles;
-  b.prob = rest / ntiles;
+  int mt;
+  if (P.xcdmap == 2) {  // N tiles fastest: the workgroups of one pixel tile sit next to each other on one XCD and share its strips in the L2
+    b.ntile = L % ntiles;
+    const int rest = L / ntiles;
+    mt = rest % total_m;
+    b.prob = rest / total_m;
+  } else {
+    mt = L % total_m;
+    const int rest = L / total_m;
+    b.ntile = rest % ntiles;
+    b.prob = rest / ntiles;
+  }
   b.img = mt / P.tiles_per_img;
   b.mtile = mt % P.tiles_per_img;
   return b;

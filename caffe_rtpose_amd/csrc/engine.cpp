@@ -1121,7 +1121,7 @@ int launch_conv_step(rtp_engine* e, Ctx& cx, const Step& s, int nimg) {
     static const char* rot = RTP_EXP_ENV("RTP_CONV_ROTATE");
     P.rotate = (rot && rot[0] == '0') ? 0 : 1;
     static const char* xm = RTP_EXP_ENV("RTP_CONV_XCDMAP");
-    P.xcdmap = (xm && xm[0] == '0') ? 0 : 1;
+    P.xcdmap = xm ? atoi(xm) : 1;
     static const char* sb = RTP_EXP_ENV("RTP_RING_SB");
     P.ring_sb = sb ? atoi(sb) : 6;
     static const char* sp = RTP_EXP_ENV("RTP_RING_SPEC");

@@ -88,7 +88,7 @@ struct ConvParams {
   int nimg;    // images (scales) in the batch
   int relu;
   int rotate;  // ring kernel: rotate the filter-row order per tile (speed only)
-  int xcdmap;  // 1: contiguous logical range per XCD (decode_block), 0: dispatch order
+  int xcdmap;  // 1: contiguous logical range per XCD, pixel tiles fastest (decode_block), 2: the same with N tiles fastest, 0: dispatch order
   int ring_sb; // ring depth request (4 or 6) where both are instantiated
   int spec;    // ring kernel: 1 = wave-specialised variant (4 DMA waves + 4 MFMA waves)
   int variant; // ring kernel experiments (env RTP_RING_VAR; see conv_ring.hip), 0 = production
