@@ -74,14 +74,19 @@ def min_bytes(ln):
 
 fs, ng, nbt = per_step(fetch_dir, "FETCH_SIZE")
 ws, ng2, _ = per_step(write_dir, "WRITE_SIZE")
+# optional: argv[7] / argv[8] = directories of SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES passes -> chip-wide MFMA pipe utilisation per launch
+# (MFMA_BUSY sums the 1024 SIMDs' busy cycles, SQ_BUSY the 32 shader engines' cycles with the launch resident)
+mf = per_step(sys.argv[7], "SQ_VALU_MFMA_BUSY_CYCLES")[0] if len(sys.argv) > 8 else None
+sq = per_step(sys.argv[8], "SQ_BUSY_CYCLES")[0] if len(sys.argv) > 8 else None
 print(f"# {ng} / {ng2} batches of {nbt} matched the plan's {len(plan)} launches (B={B}, scales={N}, {sys.argv[5]}, {model}); FETCH_SIZE x2 + WRITE_SIZE, KiB -> MB")
-print(f"# {'fetch MB':>9s} {'write MB':>9s} {'total MB':>9s} {'fp16 min MB':>11s} {'ratio':>6s} {'us(pmc)':>8s} {'GB/s':>7s} {'of 8 TB/s':>9s}  step")
+print(f"# {'fetch MB':>9s} {'write MB':>9s} {'total MB':>9s} {'fp16 min MB':>11s} {'ratio':>6s} {'us(pmc)':>8s} {'GB/s':>7s} {'of 8 TB/s':>9s}{' mfma_busy' if mf else ''}  step")
 tot = [0.0, 0.0, 0.0, 0.0]
-for ln, (f, d, _), (w, d2, _) in zip(plan, fs, ws):
+for si, (ln, (f, d, _), (w, d2, _)) in enumerate(zip(plan, fs, ws)):
     fb, wb = 2 * f * 1024, w * 1024
     mb = min_bytes(ln)
     us = d / 1e3 if d else 0.0
     gbs = (fb + wb) / (us * 1e-6) / 1e9 if us else 0.0
     tot[0] += fb; tot[1] += wb; tot[2] += mb; tot[3] += us
-    print(f"  {fb / 1e6:9.2f} {wb / 1e6:9.2f} {(fb + wb) / 1e6:9.2f} {mb / 1e6:11.2f} {(fb + wb) / mb if mb else 0:6.2f} {us:8.1f} {gbs:7.0f} {gbs / 8000:9.3f}  {ln[5:110]}")
+    util = f" {mf[si][0] / (32.0 * sq[si][0]):9.3f}" if mf and sq and sq[si][0] > 0 else ""
+    print(f"  {fb / 1e6:9.2f} {wb / 1e6:9.2f} {(fb + wb) / 1e6:9.2f} {mb / 1e6:11.2f} {(fb + wb) / mb if mb else 0:6.2f} {us:8.1f} {gbs:7.0f} {gbs / 8000:9.3f}{util}  {ln[5:110]}")
 print(f"# batch: fetch {tot[0] / 1e6:.1f} MB + write {tot[1] / 1e6:.1f} MB = {(tot[0] + tot[1]) / 1e6:.1f} MB against {tot[2] / 1e6:.1f} MB of fp16 tensors; {tot[3]:.0f} us of launches under the counter pass")
